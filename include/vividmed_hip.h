@@ -1,0 +1,280 @@
+/*
+ * vividmed_hip.h — C ABI of libvividmed_hip.so (gfx950 / MI355X).
+ *
+ * This is the "B-inner" boundary of SURVEY.md §8(b): the reference
+ * (function2-llx/MMMM) has no FFI of its own — its hot path is Python calling
+ * torch/xformers/peft ops — so every entry point below replaces one *op site*
+ * of the reference training step, cited as `file:line` into /root/reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`.
+ *   - matrices are row-major with an explicit leading dimension (elements).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it,
+ *     nothing synchronises, nothing allocates (graph-capture safe).
+ *   - return value: 0 = ok, negative = VM_ERR_* (never throws).
+ *   - `nrows_dev`: optional device pointer to an int32 row count that is
+ *     produced on the device (e.g. number of valid / vision-expert tokens).
+ *     When non-NULL the host-side `rows` argument is only an upper bound used
+ *     to size the grid; kernels read the true count from the device, so no
+ *     host synchronisation is needed (SURVEY.md §7 "index lists must be built
+ *     on-device without a host sync").
+ */
+#ifndef VIVIDMED_HIP_H
+#define VIVIDMED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VM_OK 0
+#define VM_ERR_BAD_ARG (-1)
+#define VM_ERR_UNSUPPORTED (-2)
+#define VM_ERR_LAUNCH (-3)
+
+/* element types */
+#define VM_BF16 0
+#define VM_F32 1
+
+/* GEMM epilogue activations */
+#define VM_ACT_NONE 0
+#define VM_ACT_GELU 1 /* exact erf GELU (torch nn.GELU / ACT2FN['gelu']) */
+#define VM_ACT_RELU 2
+
+/* library / device info --------------------------------------------------- */
+int vm_version(void);
+/* fills name[0..len) with the gcnArchName of the current device */
+int vm_device_arch(char* name_host, int len);
+
+/* per-kernel profiling with HIP events (used by bench.py for `roofline`).
+ * When enabled, every vm_gemm_* launch is bracketed by two events recorded on
+ * the launch stream; vm_prof_collect synchronises those events and returns the
+ * summed duration and the summed algorithmic FLOPs. */
+int vm_prof_enable(int on);
+int vm_prof_reset(void);
+int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, int64_t* launches_host);
+#define VM_PROF_GEMM_BF16 0
+#define VM_PROF_GEMM_F32 1
+#define VM_PROF_ATTN 2
+
+/* ------------------------------------------------------------------------
+ * Token routing metadata.
+ * Replaces: get_expert_mask            mmmm/models/cogvlm/modeling_cogvlm.py:58-70
+ *           boolean gather/scatter     modeling_cogvlm.py:243-245,277-279,95-97
+ *           _to_tensor_list / padding  modeling_cogvlm.py:100-128
+ *
+ * Input  token_type_ids[B,L] int64, attention_mask[B,L] (int64, 0/1).
+ * Output (all int32, device):
+ *   counts[4]      = { n_vision_rows, n_total_rows, max_seqlen, 0 }
+ *   row_of_tok[B*L]  packed row of token (b,l), -1 for padding.
+ *                    rows [0,n_vision) are vision-expert tokens, rows
+ *                    [n_vision,n_total) language-expert tokens; inside each
+ *                    segment tokens keep (b,l) order.
+ *   tok_of_row[B*L]  inverse map (b*L+l), -1 for rows >= n_total
+ *   cu_seqlens[B+1]  prefix sums of valid tokens per sample
+ *   row_of_pos[B*L]  row of the i-th valid token of sample b at index cu_seqlens[b]+i
+ *                    (what the var-len attention kernel gathers through)
+ *   expert_mask[B*L] uint8: bit0 = vision expert, bit1 = language expert
+ *                    (bit-exact restatement of get_expert_mask)
+ * One workgroup, no host sync.
+ */
+int vm_expert_index_build(const int64_t* token_type_ids, const int64_t* attention_mask,
+                          int B, int L,
+                          int32_t* counts, int32_t* row_of_tok, int32_t* tok_of_row,
+                          int32_t* cu_seqlens, int32_t* row_of_pos, uint8_t* expert_mask, void* stream);
+
+/* ------------------------------------------------------------------------
+ * bf16 MFMA GEMM, "NT" form:  C[M,N] = act( A[M,K]·B[N,K]^T + ext + bias ) + residual
+ * Replaces every nn.Linear on the path: visual.py:93,100,120-122,174-177;
+ * modeling_cogvlm.py:55,244-245,278-279,701; peft lora.Linear (conf/lora.yaml).
+ *
+ * Two-segment grouped form (token-type gated experts, modeling_cogvlm.py:87-98,
+ * 243-245, 277-279): rows [0,split) use B/bias/B2, rows [split,M) use
+ * B_1/bias_1/B2_1. `split`/`M` may come from the device (counts_dev[0],
+ * counts_dev[1]) — then M is the grid upper bound.
+ *
+ * K-extension (LoRA, K14): ext = alpha2 * A2[M,K2]·B2[N,K2]^T accumulated in the
+ * same fp32 accumulator ( y = W x + s·B(A x) with A2 = A x precomputed ).
+ * If drop_p > 0 the extension part of the accumulator is multiplied by the
+ * inverted-dropout mask of element (row, col) (used by the LoRA dgrad).
+ *
+ * Requirements: K % 64 == 0, K2 % 64 == 0, lda/ldb/lda2/ldb2 % 8 == 0, ldc % 4 == 0,
+ * all base pointers 16-byte aligned. M, N arbitrary. bias/residual have the dtype of C.
+ */
+typedef struct vm_gemm_args {
+  const void* A; int64_t lda;
+  const void* B; const void* B_1; int64_t ldb;
+  const void* A2; int64_t lda2;
+  const void* B2; const void* B2_1; int64_t ldb2;
+  int32_t K2; float alpha2;
+  const void* bias; const void* bias_1;      /* [N], same dtype as C, or NULL */
+  const void* residual; int64_t ldr;         /* [M,N] dtype of C, or NULL */
+  void* C; int64_t ldc;
+  int32_t M, N, K;
+  const int32_t* counts_dev;                 /* NULL, or {split, M_true} on device */
+  int32_t split;                             /* host-side split when counts_dev == NULL; <0 = single segment */
+  int32_t act;                               /* VM_ACT_* */
+  int32_t out_dtype;                         /* VM_BF16 or VM_F32 */
+  float drop_p; uint64_t drop_seed;          /* dropout on the extension accumulator */
+  float alpha;                               /* scale on the main product (1.0 default) */
+} vm_gemm_args;
+
+int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);
+
+/* fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fma chain). Same NT form and
+ * argument struct (all dtypes f32; K % 32 == 0, K2 % 32 == 0, ld % 4 == 0). Used by the fp32 islands
+ * `sam`, `isam_model`, `vg_proj` (mmmm/models/mmmm.py:137-138). */
+int vm_gemm_f32(const vm_gemm_args* args_host, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Row-wise kernels (HBM-bound). `dtype` is the storage type of x/y/dx/dy;
+ * statistics and accumulation are fp32.
+ */
+
+/* RMSNorm — modeling_cogvlm.py:30-41 (fp32 maths, weight in `dtype`).
+ * rstd[rows] (fp32) is saved for the backward. */
+int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd,
+                   int rows, int cols, float eps, int dtype,
+                   const int32_t* nrows_dev, void* stream);
+/* dx = d/dx ; dw_partial is an fp32 [cols] accumulator (atomically added to, must be zeroed by the caller) */
+int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd,
+                   void* dx, float* dw_accum,
+                   int rows, int cols, int dtype,
+                   const int32_t* nrows_dev, void* stream);
+
+/* LayerNorm (+ optional residual): y = residual + LN(x)*w + b
+ * visual.py:129-141 (post-LN on the branch output), image_encoder.py:121-124,
+ * transformer.py:743-753, mask_decoder.py:15-26. */
+int vm_layernorm_fwd(const void* x, const void* w, const void* b, const void* residual,
+                     void* y, float* mean, float* rstd,
+                     int rows, int cols, float eps, int dtype, void* stream);
+int vm_layernorm_bwd(const void* x, const void* w, const void* dy,
+                     const float* mean, const float* rstd,
+                     void* dx, float* dw_accum, float* db_accum,
+                     int rows, int cols, int dtype, void* stream);
+
+/* RoPE, rotate_half form, looked up by explicit position ids —
+ * modeling_cogvlm.py:183-193. In place on q and k inside a packed qkv buffer
+ * [rows, 3*H*hd] (q at col 0, k at col H*hd). cos/sin: fp32 tables [n_pos, hd]
+ * built on the host exactly as modeling_cogvlm.py:162-170 does (so the
+ * bf16 `inv_freq` quirk of SURVEY.md §7 is reproduced by construction).
+ * inverse != 0 applies the transposed rotation (the backward). */
+int vm_rope_inplace(void* qkv, int64_t ld, const int32_t* row_pos,
+                    const float* cos_tab, const float* sin_tab, int n_pos,
+                    int rows, int n_heads, int head_dim, int dtype, int inverse,
+                    const int32_t* nrows_dev, void* stream);
+
+/* SwiGLU gate: out = silu(gate) * up — modeling_cogvlm.py:55, visual.py:176 */
+int vm_silu_mul_fwd(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
+int vm_silu_mul_bwd(const void* gate, const void* up, const void* dout,
+                    void* dgate, void* dup, int64_t n, int dtype, void* stream);
+
+/* exact GELU — visual.py:121,175; image_encoder.py MLP; mask_decoder.py:287-289 */
+int vm_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int vm_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+int vm_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
+/* inverted dropout with a counter-based hash RNG: y = x * keep(seed, i) / (1-p)
+ * (peft lora.Linear lora_dropout, conf/lora.yaml:3). Same (seed, index) ->
+ * same mask, so gradient-checkpoint recompute and backward regenerate it. */
+int vm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+
+/* y = a + b (residual adds kept on our own stream/kernel set) */
+int vm_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+/* dtype conversion */
+int vm_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream);
+
+/* out[r, :] = src[idx[r], :] (idx < 0 -> zeros). Embedding lookup
+ * (modeling_cogvlm.py:449) and packed<->padded layout changes. */
+int vm_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out,
+                   int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
+/* out[idx[r], :] = src[r, :] for idx[r] >= 0 (image-feature scatter,
+ * modeling_cogvlm.py:451-453; attention output scatter :126) */
+int vm_scatter_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out,
+                    int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
+/* Embedding weight gradient: rows sorted by id; one workgroup per segment head
+ * sums its rows in fp32 (deterministic, no atomics). */
+int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, const int32_t* sorted_rows,
+                     int n, void* dweight, int64_t ld_w, int cols, int dtype, void* stream);
+
+/* out[c, r] = in[r, c]; columns >= rows_true (device count, optional) are zero-filled
+ * up to `rows` so that the result can be the K-contiguous operand of an NT GEMM
+ * (weight-gradient GEMMs contract over tokens). */
+int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                 int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Per-token weighted cross-entropy over the vocabulary —
+ * _sample_weighted_ce, modeling_cogvlm.py:610-627, fed by lm_head :701.
+ * logits [rows, vocab] (ld elements) in `dtype`; maths fp32.
+ * fwd: row_loss[r] = lse_r - logit[r,label_r] (0 if label == -100); lse saved.
+ * bwd: dlogits[r,j] = (softmax_rj - [j==label_r]) * row_scale[r]; row_scale is
+ *      weight_r / n_valid * dloss, prepared by the host wrapper on the device.
+ */
+int vm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_loss, float* lse,
+              int rows, int vocab, int dtype, const int32_t* nrows_dev, void* stream);
+int vm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* lse,
+              const float* row_scale, void* dlogits, int64_t ld_d,
+              int rows, int vocab, int dtype, const int32_t* nrows_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Variable-length (block-diagonal) flash attention, bf16 MFMA, fp32 softmax.
+ * Replaces the four xformers memory_efficient_attention sites:
+ *   modeling_cogvlm.py:113-128 (BlockDiagonalCausalMask, hd 128)
+ *   visual.py:91-99            (BlockDiagonalMask, hd 112, scale 112^-0.5)
+ * q,k,v: [rows, H, hd] views with row strides ldq/ldk/ldv (elements); they may
+ * alias one packed qkv buffer. Sequences are given by cu_seqlens[n_seq+1] over
+ * *sequence positions*; `row_of_pos` (optional) maps a sequence position to
+ * its physical row (expert-sorted layout), NULL = identity.
+ * out: [rows, H, hd] (ldo), lse: [H, total_pos] fp32.
+ */
+typedef struct vm_attn_args {
+  const void* q; const void* k; const void* v; void* out;
+  int64_t ldq, ldk, ldv, ldo;
+  float* lse;
+  const int32_t* cu_seqlens; int32_t n_seq;
+  const int32_t* row_of_pos;
+  int32_t total_pos_max;   /* upper bound of cu_seqlens[n_seq] (grid sizing) */
+  int32_t max_seqlen;      /* upper bound of any sequence length */
+  int32_t n_heads, head_dim;
+  float scale;
+  int32_t causal;
+  /* backward only */
+  const void* dout; int64_t lddo;
+  void* dq; void* dk; void* dv; int64_t lddq, lddk, lddv;
+  float* delta;            /* [H, total_pos] scratch: rowsum(dO*O) */
+} vm_attn_args;
+int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
+int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
+
+/* fp32 attention (SAM ViT-B encoder image_encoder.py:126-136 hd 64; two-way
+ * transformer transformer.py:224-239 hd 96/48, tiny Lq or tiny Lk).
+ * Dense batched form: q [Bn, Lq, H, hd], k/v [Bn, Lk, H, hd] given by strides. */
+typedef struct vm_attn_f32_args {
+  const float* q; const float* k; const float* v; float* out;
+  int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;   /* batch / position strides (elements); head stride = hd */
+  float* lse;              /* [Bn, H, Lq] */
+  int32_t Bn, Lq, Lk, n_heads, head_dim;
+  float scale;
+  const int32_t* cu_seqlens; int32_t n_seq;  /* optional varlen (self-attention, Bn == 1) */
+  /* backward */
+  const float* dout; int64_t do_bs, do_ls;
+  float* dq; float* dk; float* dv;           /* same strides as q/k/v */
+  float* delta;
+} vm_attn_f32_args;
+int vm_attn_fwd_f32(const vm_attn_f32_args* args_host, void* stream);
+int vm_attn_bwd_f32(const vm_attn_f32_args* args_host, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Patch embedding im2col — visual.py:64 / resample.py:55-62 /
+ * image_encoder.py:72. image [C, D, H, W] -> cols [n_patch, C*pz*py*px]
+ * (K order c,z,y,x = conv3d weight.flatten(1)), patch order d,h,w. */
+int vm_im2col3d(const void* image, int C, int D, int H, int W, int pz, int py, int px,
+                void* cols, int64_t ld, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIVIDMED_HIP_H */

@@ -1,0 +1,744 @@
+// Row-wise / element-wise HBM-bound kernels of the VividMed training step.
+// One wavefront (64 lanes) owns one row; 16-byte vector accesses; fp32 maths.
+// Reference op sites are cited per entry point in include/vividmed_hip.h.
+#include "vm_common.hpp"
+
+namespace {
+
+constexpr int ROW_WAVES = 4;          // waves (= rows in flight) per workgroup
+constexpr int ROW_THREADS = ROW_WAVES * 64;
+constexpr int MAX_PARTIAL = 64;       // fp32 partials per lane for dw/db accumulation (cols <= 4096)
+
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::vec_t ldv(const T* p) {
+  return *reinterpret_cast<const typename Elem<T>::vec_t*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void stv(T* p, typename Elem<T>::vec_t v) {
+  *reinterpret_cast<typename Elem<T>::vec_t*>(p) = v;
+}
+
+// ---------------------------------------------------------------- RMSNorm
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_fwd_k(
+    const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, float* __restrict__ rstd_out,
+    int rows, int cols, float eps, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  T* yr = y + (int64_t)row * cols;
+  float ss = 0.f;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto v = ldv<T>(xr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { float f = Elem<T>::ld(v[i]); ss += f * f; }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = r;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto v = ldv<T>(xr + c);
+    auto wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = Elem<T>::st(Elem<T>::ld(wv[i]) * (Elem<T>::ld(v[i]) * r));
+    stv<T>(yr + c, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
+    const float* __restrict__ rstd, T* __restrict__ dx, float* __restrict__ dw_accum,
+    int rows, int cols, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  constexpr int NP = MAX_PARTIAL / V;  // passes supported
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  float part[MAX_PARTIAL];
+#pragma unroll
+  for (int i = 0; i < MAX_PARTIAL; ++i) part[i] = 0.f;
+  const float inv_cols = 1.0f / (float)cols;
+  for (int row = blockIdx.x * ROW_WAVES + wid; row < rows; row += gridDim.x * ROW_WAVES) {
+    const T* xr = x + (int64_t)row * cols;
+    const T* dyr = dy + (int64_t)row * cols;
+    T* dxr = dx + (int64_t)row * cols;
+    const float r = rstd[row];
+    float dot = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + lane) * V;
+      if (c < cols) {
+        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = Elem<T>::ld(xv[i]) * r, g = Elem<T>::ld(gv[i]);
+          dot += Elem<T>::ld(wv[i]) * g * xh;
+          part[p * V + i] += g * xh;
+        }
+      }
+    }
+    dot = wave_sum(dot) * inv_cols;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + lane) * V;
+      if (c < cols) {
+        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
+        typename Elem<T>::vec_t o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = Elem<T>::ld(xv[i]) * r;
+          o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) - xh * dot));
+        }
+        stv<T>(dxr + c, o);
+      }
+    }
+  }
+  if (dw_accum) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + lane) * V;
+      if (c < cols) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) atomicAdd(dw_accum + c + i, part[p * V + i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b, const T* __restrict__ res,
+    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    int rows, int cols, float eps) {
+  constexpr int V = Elem<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  float s = 0.f;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto v = ldv<T>(xr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += Elem<T>::ld(v[i]);
+  }
+  const float mu = wave_sum(s) / (float)cols;
+  float ss = 0.f;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto v = ldv<T>(xr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { const float d = Elem<T>::ld(v[i]) - mu; ss += d * d; }
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)cols + eps);
+  if (lane == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = r; }
+  T* yr = y + (int64_t)row * cols;
+  const T* rr = res ? res + (int64_t)row * cols : nullptr;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto v = ldv<T>(xr + c);
+    typename Elem<T>::vec_t o;
+    typename Elem<T>::vec_t wv, bv, rv;
+    if (w) wv = ldv<T>(w + c);
+    if (b) bv = ldv<T>(b + c);
+    if (rr) rv = ldv<T>(rr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float f = (Elem<T>::ld(v[i]) - mu) * r;
+      if (w) f *= Elem<T>::ld(wv[i]);
+      if (b) f += Elem<T>::ld(bv[i]);
+      // torch rounds LN's output to the storage dtype before the residual add
+      if (rr) f = Elem<T>::ld(Elem<T>::st(f)) + Elem<T>::ld(rv[i]);
+      o[i] = Elem<T>::st(f);
+    }
+    stv<T>(yr + c, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    T* __restrict__ dx, float* __restrict__ dw_accum, float* __restrict__ db_accum,
+    int rows, int cols) {
+  constexpr int V = Elem<T>::VEC;
+  constexpr int NP = MAX_PARTIAL / V;
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  float pw[MAX_PARTIAL], pb[MAX_PARTIAL];
+#pragma unroll
+  for (int i = 0; i < MAX_PARTIAL; ++i) { pw[i] = 0.f; pb[i] = 0.f; }
+  const float inv_cols = 1.0f / (float)cols;
+  for (int row = blockIdx.x * ROW_WAVES + wid; row < rows; row += gridDim.x * ROW_WAVES) {
+    const T* xr = x + (int64_t)row * cols;
+    const T* dyr = dy + (int64_t)row * cols;
+    T* dxr = dx + (int64_t)row * cols;
+    const float mu = mean[row], r = rstd[row];
+    float s1 = 0.f, s2 = 0.f;  // sum(w*dy), sum(w*dy*xhat)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + lane) * V;
+      if (c < cols) {
+        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
+        typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
+          const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+          s1 += wg; s2 += wg * xh;
+          pw[p * V + i] += g * xh; pb[p * V + i] += g;
+        }
+      }
+    }
+    s1 = wave_sum(s1) * inv_cols; s2 = wave_sum(s2) * inv_cols;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c = (p * 64 + lane) * V;
+      if (c < cols) {
+        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
+        typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
+        typename Elem<T>::vec_t o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
+          const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+          o[i] = Elem<T>::st(r * (wg - s1 - xh * s2));
+        }
+        stv<T>(dxr + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c = (p * 64 + lane) * V;
+    if (c < cols) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        if (dw_accum) atomicAdd(dw_accum + c + i, pw[p * V + i]);
+        if (db_accum) atomicAdd(db_accum + c + i, pb[p * V + i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- RoPE
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void rope_k(
+    T* __restrict__ qkv, int64_t ld, const int32_t* __restrict__ row_pos,
+    const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int n_pos,
+    int rows, int n_heads, int hd, int inverse, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int pos = row_pos[row];
+  pos = max(0, min(pos, n_pos - 1));
+  const float* cr = cos_tab + (int64_t)pos * hd;
+  const float* sr = sin_tab + (int64_t)pos * hd;
+  const int half = hd >> 1;
+  const int cph = half / V;                    // chunks per half head
+  const int items = 2 * n_heads * cph;         // q and k
+  T* base = qkv + (int64_t)row * ld;
+  for (int it = lane; it < items; it += 64) {
+    const int ch = it % cph;
+    const int head = (it / cph) % n_heads;
+    const int which = it / (cph * n_heads);    // 0 = q, 1 = k
+    T* p1 = base + (int64_t)which * n_heads * hd + head * hd + ch * V;
+    T* p2 = p1 + half;
+    auto a = ldv<T>(p1); auto b = ldv<T>(p2);
+    typename Elem<T>::vec_t oa, ob;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      // table holds cat(freqs, freqs): entry i and i+half are equal, but keep both lookups literal
+      const float c1 = cr[ch * V + i], s1 = sr[ch * V + i];
+      const float c2 = cr[half + ch * V + i], s2 = sr[half + ch * V + i];
+      const float x1 = Elem<T>::ld(a[i]), x2 = Elem<T>::ld(b[i]);
+      if (!inverse) {
+        // out = x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
+        oa[i] = Elem<T>::st(x1 * c1 - x2 * s1);
+        ob[i] = Elem<T>::st(x2 * c2 + x1 * s2);
+      } else {
+        // transposed map: dx1 = g1*c1 + g2*s2 ; dx2 = g2*c2 - g1*s1
+        oa[i] = Elem<T>::st(x1 * c1 + x2 * s2);
+        ob[i] = Elem<T>::st(x2 * c2 - x1 * s1);
+      }
+    }
+    stv<T>(p1, oa); stv<T>(p2, ob);
+  }
+}
+
+// ---------------------------------------------------------------- elementwise
+enum { EW_SILU_MUL_F, EW_GELU_F, EW_GELU_B, EW_RELU_B, EW_ADD, EW_DROPOUT };
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_k(const T* __restrict__ a, const T* __restrict__ b,
+                                            T* __restrict__ y, int64_t n, float p, uint64_t seed) {
+  constexpr int V = Elem<T>::VEC;
+  const int64_t nv = n / V;
+  const float inv_keep = 1.0f / (1.0f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    auto av = ldv<T>(a + i * V);
+    typename Elem<T>::vec_t bv;
+    if (OP == EW_SILU_MUL_F || OP == EW_GELU_B || OP == EW_RELU_B || OP == EW_ADD) bv = ldv<T>(b + i * V);
+    typename Elem<T>::vec_t o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float x = Elem<T>::ld(av[j]);
+      float r;
+      if (OP == EW_SILU_MUL_F) {
+        // reference rounds silu(gate) to the storage dtype before the product (modeling_cogvlm.py:55)
+        const float s = Elem<T>::ld(Elem<T>::st(x / (1.0f + __expf(-x))));
+        r = s * Elem<T>::ld(bv[j]);
+      } else if (OP == EW_GELU_F) r = gelu_erf(x);
+      else if (OP == EW_GELU_B) r = gelu_erf_grad(x) * Elem<T>::ld(bv[j]);
+      else if (OP == EW_RELU_B) r = x > 0.f ? Elem<T>::ld(bv[j]) : 0.f;
+      else if (OP == EW_ADD) r = x + Elem<T>::ld(bv[j]);
+      else /* EW_DROPOUT */ r = vm_keep(seed, (uint64_t)(i * V + j), p) ? x * inv_keep : 0.f;
+      o[j] = Elem<T>::st(r);
+    }
+    stv<T>(y + i * V, o);
+  }
+  // scalar tail
+  const int64_t t0 = nv * V;
+  for (int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = Elem<T>::ld(a[i]);
+    float r;
+    if (OP == EW_SILU_MUL_F) r = Elem<T>::ld(Elem<T>::st(x / (1.0f + __expf(-x)))) * Elem<T>::ld(b[i]);
+    else if (OP == EW_GELU_F) r = gelu_erf(x);
+    else if (OP == EW_GELU_B) r = gelu_erf_grad(x) * Elem<T>::ld(b[i]);
+    else if (OP == EW_RELU_B) r = x > 0.f ? Elem<T>::ld(b[i]) : 0.f;
+    else if (OP == EW_ADD) r = x + Elem<T>::ld(b[i]);
+    else r = vm_keep(seed, (uint64_t)i, p) ? x * inv_keep : 0.f;
+    y[i] = Elem<T>::st(r);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_bwd_k(const T* __restrict__ g, const T* __restrict__ u,
+                                                      const T* __restrict__ dout, T* __restrict__ dg,
+                                                      T* __restrict__ du, int64_t n) {
+  constexpr int V = Elem<T>::VEC;
+  const int64_t nv = n / V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    auto gv = ldv<T>(g + i * V); auto uv = ldv<T>(u + i * V); auto dv = ldv<T>(dout + i * V);
+    typename Elem<T>::vec_t og, ou;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float x = Elem<T>::ld(gv[j]), uu = Elem<T>::ld(uv[j]), d = Elem<T>::ld(dv[j]);
+      const float sig = 1.0f / (1.0f + __expf(-x));
+      const float s = x * sig;
+      ou[j] = Elem<T>::st(d * s);
+      og[j] = Elem<T>::st(d * uu * (sig * (1.0f + x * (1.0f - sig))));
+    }
+    stv<T>(dg + i * V, og); stv<T>(du + i * V, ou);
+  }
+  const int64_t t0 = nv * V;
+  for (int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = Elem<T>::ld(g[i]), uu = Elem<T>::ld(u[i]), d = Elem<T>::ld(dout[i]);
+    const float sig = 1.0f / (1.0f + __expf(-x));
+    du[i] = Elem<T>::st(d * x * sig);
+    dg[i] = Elem<T>::st(d * uu * (sig * (1.0f + x * (1.0f - sig))));
+  }
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_k(const S* __restrict__ x, D* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = Elem<D>::st(Elem<S>::ld(x[i]));
+}
+
+// ---------------------------------------------------------------- row gather / scatter
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(ROW_THREADS) void move_rows_k(
+    const T* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
+    T* __restrict__ out, int64_t ld_out, int rows, int cols, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int j = idx[row];
+  if (SCATTER) {
+    if (j < 0) return;
+    const T* s = src + (int64_t)row * ld_src;
+    T* d = out + (int64_t)j * ld_out;
+    for (int c = lane * V; c < cols; c += 64 * V) stv<T>(d + c, ldv<T>(s + c));
+  } else {
+    T* d = out + (int64_t)row * ld_out;
+    if (j < 0) {
+      typename Elem<T>::vec_t z;
+#pragma unroll
+      for (int i = 0; i < V; ++i) z[i] = Elem<T>::st(0.f);
+      for (int c = lane * V; c < cols; c += 64 * V) stv<T>(d + c, z);
+    } else {
+      const T* s = src + (int64_t)j * ld_src;
+      for (int c = lane * V; c < cols; c += 64 * V) stv<T>(d + c, ldv<T>(s + c));
+    }
+  }
+}
+
+// Embedding weight gradient: position p (in id-sorted order) that starts a segment sums the segment.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_k(
+    const T* __restrict__ dout, int64_t ld, const int32_t* __restrict__ sorted_ids,
+    const int32_t* __restrict__ sorted_rows, int n, T* __restrict__ dw, int64_t ld_w, int cols) {
+  const int p = blockIdx.x;
+  const int id = sorted_ids[p];
+  if (id < 0) return;
+  if (p > 0 && sorted_ids[p - 1] == id) return;  // not a segment head
+  int e = p + 1;
+  while (e < n && sorted_ids[e] == id) ++e;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float acc = 0.f;
+    for (int q = p; q < e; ++q) {
+      const int r = sorted_rows[q];
+      if (r >= 0) acc += Elem<T>::ld(dout[(int64_t)r * ld + c]);
+    }
+    dw[(int64_t)id * ld_w + c] = Elem<T>::st(acc);
+  }
+}
+
+// ---------------------------------------------------------------- transpose (64x64 tiles through LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int64_t ld_in,
+                                                   T* __restrict__ out, int64_t ld_out,
+                                                   int rows, int cols, const int32_t* nrows_dev) {
+  __shared__ T tile[64][64 + 2];
+  int rows_true = rows;
+  if (nrows_dev) rows_true = min(rows, *nrows_dev);
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    T v = Elem<T>::st(0.f);
+    if (r < rows_true && c < cols) v = in[(int64_t)r * ld_in + c];
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------- cross entropy
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_k(const T* __restrict__ logits, int64_t ld,
+                                                const int64_t* __restrict__ labels,
+                                                float* __restrict__ row_loss, float* __restrict__ lse_out,
+                                                int rows, int vocab, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  __shared__ float red[16];
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  const T* lr = logits + (int64_t)row * ld;
+  const int nv = vocab / V;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    auto v = ldv<T>(lr + i * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) m = fmaxf(m, Elem<T>::ld(v[j]));
+  }
+  for (int i = nv * V + threadIdx.x; i < vocab; i += blockDim.x) m = fmaxf(m, Elem<T>::ld(lr[i]));
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    auto v = ldv<T>(lr + i * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) s += __expf(Elem<T>::ld(v[j]) - m);
+  }
+  for (int i = nv * V + threadIdx.x; i < vocab; i += blockDim.x) s += __expf(Elem<T>::ld(lr[i]) - m);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float lse = m + __logf(s);
+    lse_out[row] = lse;
+    const int64_t lab = labels[row];
+    row_loss[row] = (lab >= 0 && lab < vocab) ? lse - Elem<T>::ld(lr[lab]) : 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_k(const T* __restrict__ logits, int64_t ld,
+                                                const int64_t* __restrict__ labels,
+                                                const float* __restrict__ lse, const float* __restrict__ row_scale,
+                                                T* __restrict__ dlogits, int64_t ld_d,
+                                                int rows, int vocab, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  int rows_true = rows;
+  if (nrows_dev) rows_true = min(rows, *nrows_dev);
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  T* dr = dlogits + (int64_t)row * ld_d;
+  const int nvd = (int)(ld_d / V);
+  if (row >= rows_true) {  // keep padded rows exactly zero: they are contracted over by the lm_head wgrad
+    typename Elem<T>::vec_t z;
+#pragma unroll
+    for (int j = 0; j < V; ++j) z[j] = Elem<T>::st(0.f);
+    for (int i = threadIdx.x; i < nvd; i += blockDim.x) stv<T>(dr + i * V, z);
+    return;
+  }
+  const T* lr = logits + (int64_t)row * ld;
+  const float l = lse[row];
+  const float sc = row_scale[row];
+  const int64_t lab = labels[row];
+  const int nv = vocab / V;
+  for (int i = threadIdx.x; i < nvd; i += blockDim.x) {
+    typename Elem<T>::vec_t o;
+    if (i < nv && sc != 0.f) {
+      auto v = ldv<T>(lr + i * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float p = __expf(Elem<T>::ld(v[j]) - l);
+        if ((int64_t)(i * V + j) == lab) p -= 1.0f;
+        o[j] = Elem<T>::st(p * sc);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const int c = i * V + j;
+        float p = 0.f;
+        if (c < vocab && sc != 0.f) { p = __expf(Elem<T>::ld(lr[c]) - l); if (c == lab) p -= 1.0f; p *= sc; }
+        o[j] = Elem<T>::st(p);
+      }
+    }
+    stv<T>(dr + i * V, o);
+  }
+}
+
+// ---------------------------------------------------------------- im2col (patch embedding)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3d_k(const T* __restrict__ img, int C, int D, int H, int W,
+                                                  int pz, int py, int px, T* __restrict__ cols, int64_t ld) {
+  const int gd = D / pz, gh = H / py, gw = W / px;
+  const int patch = blockIdx.x;
+  if (patch >= gd * gh * gw) return;
+  const int pd = patch / (gh * gw), ph = (patch / gw) % gh, pw = patch % gw;
+  const int K = C * pz * py * px;
+  T* out = cols + (int64_t)patch * ld;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const int x = k % px, y = (k / px) % py, z = (k / (px * py)) % pz, c = k / (px * py * pz);
+    out[k] = img[(((int64_t)c * D + pd * pz + z) * H + ph * py + y) * W + pw * px + x];
+  }
+}
+
+inline int ew_grid(int64_t n, int vec) {
+  int64_t b = (n / vec + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, ...)                                    \
+  if ((dtype) == VM_BF16) { typedef unsigned short T; __VA_ARGS__; }  \
+  else if ((dtype) == VM_F32) { typedef float T; __VA_ARGS__; }       \
+  else return VM_ERR_BAD_ARG;
+
+extern "C" {
+
+int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps,
+                   int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_fwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)x, (const T*)w, (T*)y, rstd, rows, cols, eps, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_accum,
+                   int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec || cols > 64 * MAX_PARTIAL) return VM_ERR_UNSUPPORTED;
+  int blocks = (rows + ROW_WAVES - 1) / ROW_WAVES;
+  if (blocks > 256) blocks = 256;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_bwd_k<T>, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)x, (const T*)w, (const T*)dy, rstd, (T*)dx, dw_accum, rows, cols,
+                                           nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_layernorm_fwd(const void* x, const void* w, const void* b, const void* residual, void* y, float* mean,
+                     float* rstd, int rows, int cols, float eps, int dtype, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_fwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)x, (const T*)w, (const T*)b, (const T*)residual, (T*)y, mean, rstd,
+                                           rows, cols, eps));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_layernorm_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
+                     float* dw_accum, float* db_accum, int rows, int cols, int dtype, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec || cols > 64 * MAX_PARTIAL) return VM_ERR_UNSUPPORTED;
+  int blocks = (rows + ROW_WAVES - 1) / ROW_WAVES;
+  if (blocks > 256) blocks = 256;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_bwd_k<T>, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)x, (const T*)w, (const T*)dy, mean, rstd, (T*)dx, dw_accum,
+                                           db_accum, rows, cols));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_rope_inplace(void* qkv, int64_t ld, const int32_t* row_pos, const float* cos_tab, const float* sin_tab,
+                    int n_pos, int rows, int n_heads, int head_dim, int dtype, int inverse,
+                    const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if ((head_dim / 2) % vec || ld % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rope_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (T*)qkv, ld,
+                                           row_pos, cos_tab, sin_tab, n_pos, rows, n_heads, head_dim, inverse,
+                                           nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+#define EW_LAUNCH(OP, a, b, y, n, p, seed)                                                                       \
+  {                                                                                                              \
+    if (n <= 0) return VM_OK;                                                                                    \
+    if (!aligned16(a) || !aligned16(y) || ((b) && !aligned16(b))) return VM_ERR_BAD_ARG;                         \
+    const int vec = dtype == VM_BF16 ? 8 : 4;                                                                    \
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ew_k<T, OP>), dim3(ew_grid(n, vec)), dim3(256), 0,                 \
+                                             (hipStream_t)stream, (const T*)(a), (const T*)(b), (T*)(y), n, p, seed)); \
+    VM_LAUNCH_CHECK();                                                                                           \
+    return VM_OK;                                                                                                \
+  }
+
+int vm_silu_mul_fwd(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream)
+  EW_LAUNCH(EW_SILU_MUL_F, gate, up, out, n, 0.f, 0ull)
+int vm_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream)
+  EW_LAUNCH(EW_GELU_F, x, (const void*)nullptr, y, n, 0.f, 0ull)
+int vm_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream)
+  EW_LAUNCH(EW_GELU_B, x, dy, dx, n, 0.f, 0ull)
+int vm_relu_bwd(const void* yv, const void* dy, void* dx, int64_t n, int dtype, void* stream)
+  EW_LAUNCH(EW_RELU_B, yv, dy, dx, n, 0.f, 0ull)
+int vm_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream)
+  EW_LAUNCH(EW_ADD, a, b, y, n, 0.f, 0ull)
+int vm_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+  if (p < 0.f || p >= 1.f) return VM_ERR_BAD_ARG;
+  EW_LAUNCH(EW_DROPOUT, x, (const void*)nullptr, y, n, p, seed)
+}
+
+int vm_silu_mul_bwd(const void* gate, const void* up, const void* dout, void* dgate, void* dup, int64_t n,
+                    int dtype, void* stream) {
+  if (n <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(silu_mul_bwd_k<T>, dim3(ew_grid(n, vec)), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)gate, (const T*)up, (const T*)dout, (T*)dgate, (T*)dup, n));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream) {
+  if (n <= 0) return VM_OK;
+  dim3 grid(ew_grid(n, 1));
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == VM_BF16 && dst_dtype == VM_F32)
+    hipLaunchKernelGGL((cast_k<unsigned short, float>), grid, dim3(256), 0, s, (const unsigned short*)x, (float*)y, n);
+  else if (src_dtype == VM_F32 && dst_dtype == VM_BF16)
+    hipLaunchKernelGGL((cast_k<float, unsigned short>), grid, dim3(256), 0, s, (const float*)x, (unsigned short*)y, n);
+  else if (src_dtype == VM_F32 && dst_dtype == VM_F32)
+    hipLaunchKernelGGL((cast_k<float, float>), grid, dim3(256), 0, s, (const float*)x, (float*)y, n);
+  else if (src_dtype == VM_BF16 && dst_dtype == VM_BF16)
+    hipLaunchKernelGGL((cast_k<unsigned short, unsigned short>), grid, dim3(256), 0, s, (const unsigned short*)x,
+                       (unsigned short*)y, n);
+  else return VM_ERR_BAD_ARG;
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int rows,
+                   int cols, int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec || ld_src % vec || ld_out % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((move_rows_k<T, false>), grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)src, ld_src, idx, (T*)out, ld_out, rows, cols, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_scatter_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int rows,
+                    int cols, int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (cols % vec || ld_src % vec || ld_out % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((move_rows_k<T, true>), grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                                           (const T*)src, ld_src, idx, (T*)out, ld_out, rows, cols, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, const int32_t* sorted_rows, int n,
+                     void* dweight, int64_t ld_w, int cols, int dtype, void* stream) {
+  if (n <= 0) return VM_OK;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(embedding_bwd_k<T>, dim3(n), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)dout, ld, sorted_ids, sorted_rows, n, (T*)dweight, ld_w, cols));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
+                 const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                                           ld_in, (T*)out, ld_out, rows, cols, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_ce_fwd(const void* logits, int64_t ld, const int64_t* labels, float* row_loss, float* lse, int rows,
+              int vocab, int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (ld % vec) return VM_ERR_BAD_ARG;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_fwd_k<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)logits, ld, labels, row_loss, lse, rows, vocab, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* row_scale,
+              void* dlogits, int64_t ld_d, int rows, int vocab, int dtype, const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0) return VM_OK;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (ld % vec || ld_d % vec) return VM_ERR_BAD_ARG;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(ce_bwd_k<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)logits, ld, labels, lse, row_scale, (T*)dlogits, ld_d, rows,
+                                           vocab, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_im2col3d(const void* image, int C, int D, int H, int W, int pz, int py, int px, void* cols, int64_t ld,
+                int dtype, void* stream) {
+  if (D % pz || H % py || W % px) return VM_ERR_BAD_ARG;
+  const int n = (D / pz) * (H / py) * (W / px);
+  if (n <= 0) return VM_OK;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(im2col3d_k<T>, dim3(n), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)image, C, D, H, W, pz, py, px, (T*)cols, ld));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Shared device helpers for libvividmed_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vividmed_hip.h"
+
+#define VM_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+
+#define VM_LAUNCH_CHECK()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return VM_ERR_LAUNCH;            \
+  } while (0)
+
+// bf16 <-> f32. A plain cast lowers to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950.
+__device__ __forceinline__ float bf2f(unsigned short u) {
+  return __builtin_bit_cast(float, (unsigned int)u << 16);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// Element accessor templated on storage type: T = unsigned short (bf16 bits) or float.
+template <typename T> struct Elem;
+template <> struct Elem<unsigned short> {
+  static constexpr int VEC = 8;  // 16 B per lane
+  typedef u16x8_t vec_t;
+  static __device__ __forceinline__ float ld(unsigned short v) { return bf2f(v); }
+  static __device__ __forceinline__ unsigned short st(float f) { return f2bf(f); }
+};
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;
+  typedef f32x4_t vec_t;
+  static __device__ __forceinline__ float ld(float v) { return v; }
+  static __device__ __forceinline__ float st(float f) { return f; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 (<= 1024). `red` has >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// Counter-based RNG for dropout masks: splitmix64 of (seed, element index).
+// Returns true when the element is KEPT. Identical on every recompute.
+__device__ __forceinline__ bool vm_keep(uint64_t seed, uint64_t idx, float p) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  // 24 random bits -> uniform [0,1)
+  float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

@@ -1,0 +1,169 @@
+"""ctypes binding of the C ABI in include/vividmed_hip.h (libvividmed_hip.so).
+
+This is the only place that touches the shared library. There is NO CPU fallback: importing the
+symbols works anywhere (so the CPU test-suite can check that every declared entry point is exported),
+but calling a kernel needs a gfx950 device, and a missing library raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+import re
+
+import torch
+
+LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libvividmed_hip.so'
+HEADER_PATH = Path(__file__).resolve().parents[1] / 'include' / 'vividmed_hip.h'
+
+VM_BF16, VM_F32 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+PROF_GEMM_BF16, PROF_GEMM_F32, PROF_ATTN = 0, 1, 2
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ('A', C.c_void_p), ('lda', C.c_int64),
+        ('B', C.c_void_p), ('B_1', C.c_void_p), ('ldb', C.c_int64),
+        ('A2', C.c_void_p), ('lda2', C.c_int64),
+        ('B2', C.c_void_p), ('B2_1', C.c_void_p), ('ldb2', C.c_int64),
+        ('K2', C.c_int32), ('alpha2', C.c_float),
+        ('bias', C.c_void_p), ('bias_1', C.c_void_p),
+        ('residual', C.c_void_p), ('ldr', C.c_int64),
+        ('C', C.c_void_p), ('ldc', C.c_int64),
+        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+        ('counts_dev', C.c_void_p),
+        ('split', C.c_int32),
+        ('act', C.c_int32),
+        ('out_dtype', C.c_int32),
+        ('drop_p', C.c_float), ('drop_seed', C.c_uint64),
+        ('alpha', C.c_float),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ('q', C.c_void_p), ('k', C.c_void_p), ('v', C.c_void_p), ('out', C.c_void_p),
+        ('ldq', C.c_int64), ('ldk', C.c_int64), ('ldv', C.c_int64), ('ldo', C.c_int64),
+        ('lse', C.c_void_p),
+        ('cu_seqlens', C.c_void_p), ('n_seq', C.c_int32),
+        ('row_of_pos', C.c_void_p),
+        ('total_pos_max', C.c_int32),
+        ('max_seqlen', C.c_int32),
+        ('n_heads', C.c_int32), ('head_dim', C.c_int32),
+        ('scale', C.c_float),
+        ('causal', C.c_int32),
+        ('dout', C.c_void_p), ('lddo', C.c_int64),
+        ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p),
+        ('lddq', C.c_int64), ('lddk', C.c_int64), ('lddv', C.c_int64),
+        ('delta', C.c_void_p),
+    ]
+
+
+class AttnF32Args(C.Structure):
+    _fields_ = [
+        ('q', C.c_void_p), ('k', C.c_void_p), ('v', C.c_void_p), ('out', C.c_void_p),
+        ('q_bs', C.c_int64), ('q_ls', C.c_int64), ('k_bs', C.c_int64), ('k_ls', C.c_int64),
+        ('v_bs', C.c_int64), ('v_ls', C.c_int64), ('o_bs', C.c_int64), ('o_ls', C.c_int64),
+        ('lse', C.c_void_p),
+        ('Bn', C.c_int32), ('Lq', C.c_int32), ('Lk', C.c_int32), ('n_heads', C.c_int32), ('head_dim', C.c_int32),
+        ('scale', C.c_float),
+        ('cu_seqlens', C.c_void_p), ('n_seq', C.c_int32),
+        ('dout', C.c_void_p), ('do_bs', C.c_int64), ('do_ls', C.c_int64),
+        ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p),
+        ('delta', C.c_void_p),
+    ]
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/vividmed_hip.h."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\bint\s+(vm_\w+)\s*\(', text)))
+
+
+def _prototypes() -> dict[str, list]:
+    """argtypes for every entry point, parsed from the header (the header is the single source of truth)."""
+    text = HEADER_PATH.read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\bint\s+(vm_\w+)\s*\(([^;{]*?)\)\s*;', text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(C.c_void_p)
+                elif 'uint64_t' in a:
+                    argtypes.append(C.c_uint64)
+                elif 'int64_t' in a:
+                    argtypes.append(C.c_int64)
+                elif 'float' in a:
+                    argtypes.append(C.c_float)
+                elif 'double' in a:
+                    argtypes.append(C.c_double)
+                else:
+                    argtypes.append(C.c_int)
+        protos[name] = argtypes
+    return protos
+
+
+_lib: C.CDLL | None = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise HipExtensionMissing(
+                f'{LIB_PATH} is missing: build it with `python -m mmmm_amd.build` '
+                '(there is no CPU fallback for the VividMed hot path)'
+            )
+        _lib = C.CDLL(str(LIB_PATH))
+        for name, argtypes in _prototypes().items():
+            fn = getattr(_lib, name)
+            fn.restype = C.c_int
+            fn.argtypes = argtypes
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'VM_ERR_BAD_ARG', -2: 'VM_ERR_UNSUPPORTED', -3: 'VM_ERR_LAUNCH'}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f'{what} failed: {_ERR.get(rc, rc)}')
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return VM_BF16
+    if dt == torch.float32:
+        return VM_F32
+    raise TypeError(f'unsupported dtype {dt}')
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError('the VividMed HIP path needs device tensors (no CPU fallback)')
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Call a C-ABI entry point with raw arguments and raise on a non-zero status."""
+    fn = getattr(lib(), name)
+    check(fn(*args), name)

@@ -1,0 +1,338 @@
+"""Tensor-level wrappers of the C ABI (one Python function per entry point, no autograd).
+
+Every function enqueues on the current torch stream and returns immediately; there is no CPU path.
+`mmmm_amd.functional` builds the autograd operators of the model on top of these.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import ptr, dtype_code, stream
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ld(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D row-major view with unit inner stride"""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(
+    a: torch.Tensor, w: torch.Tensor, *,
+    w1: torch.Tensor | None = None,
+    a2: torch.Tensor | None = None, b2: torch.Tensor | None = None, b2_1: torch.Tensor | None = None,
+    alpha2: float = 1.0,
+    bias: torch.Tensor | None = None, bias1: torch.Tensor | None = None,
+    residual: torch.Tensor | None = None,
+    out: torch.Tensor | None = None, out_dtype: torch.dtype | None = None,
+    act: int = hip.ACT_NONE,
+    counts: torch.Tensor | None = None, split: int = -1,
+    drop_p: float = 0.0, drop_seed: int = 0,
+) -> torch.Tensor:
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
+
+    `w1`/`b2_1`/`bias1`: weights of the second row segment (token-type gated experts); the segment
+    boundary is `split` (host) or `counts[0]` with `counts[1]` valid rows (device int32 tensor).
+    """
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+    M, K = a.shape
+    N = w.shape[0]
+    f32 = a.dtype == torch.float32
+    assert w.dtype == a.dtype
+    if out_dtype is None:
+        out_dtype = a.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    g = hip.GemmArgs()
+    g.A, g.lda = ptr(a), _ld(a)
+    g.B, g.B_1, g.ldb = ptr(w), ptr(w1), _ld(w)
+    if w1 is not None:
+        assert w1.shape == w.shape and _ld(w1) == _ld(w)
+    if a2 is not None:
+        assert b2 is not None and a2.shape[0] == M and b2.shape == (N, a2.shape[1])
+        g.A2, g.lda2 = ptr(a2), _ld(a2)
+        g.B2, g.B2_1, g.ldb2 = ptr(b2), ptr(b2_1), _ld(b2)
+        g.K2 = a2.shape[1]
+    else:
+        g.K2 = 0
+    g.alpha2 = alpha2
+    if bias is not None:
+        assert bias.dtype == out.dtype and bias.numel() == N
+    g.bias, g.bias_1 = ptr(bias), ptr(bias1)
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape == out.shape
+        g.residual, g.ldr = ptr(residual), _ld(residual)
+    g.C, g.ldc = ptr(out), _ld(out)
+    g.M, g.N, g.K = M, N, K
+    g.counts_dev = ptr(counts)
+    g.split = split
+    g.act = act
+    g.out_dtype = dtype_code(out.dtype)
+    g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF
+    g.alpha = 1.0
+    hip.call('vm_gemm_f32' if f32 else 'vm_gemm_bf16', C.addressof(g), stream())
+    return out
+
+
+def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = None) -> torch.Tensor:
+    """out[cols, rows_padded] = x^T, zero beyond the true row count (K-contiguous operand of a wgrad GEMM)"""
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    rp = (rows + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(cols, rp, dtype=x.dtype, device=x.device)
+    if rp > rows:
+        out[:, rows:].zero_()
+    hip.call('vm_transpose', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(nrows), stream())
+    return out
+
+
+# ------------------------------------------------------------------ norms
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tensor | None = None):
+    x = _c(x)
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    hip.call('vm_rmsnorm_fwd', ptr(x), ptr(w), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x.dtype), ptr(nrows), stream())
+    return y, rstd
+
+
+def rmsnorm_bwd(x, w, dy, rstd, nrows: torch.Tensor | None = None, need_dw: bool = True):
+    x, dy = _c(x), _c(dy)
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_dw else None
+    hip.call('vm_rmsnorm_bwd', ptr(x), ptr(w), ptr(dy), ptr(rstd), ptr(dx), ptr(dw), rows, cols, dtype_code(x.dtype), ptr(nrows), stream())
+    return dx, dw
+
+
+def layernorm_fwd(x, w, b, eps: float, residual: torch.Tensor | None = None):
+    x = _c(x)
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    hip.call('vm_layernorm_fwd', ptr(x), ptr(w), ptr(b), ptr(residual), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
+             dtype_code(x.dtype), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, w, dy, mean, rstd, need_dw: bool = True):
+    x, dy = _c(x), _c(dy)
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_dw else None
+    db = torch.zeros(cols, dtype=torch.float32, device=x.device) if need_dw else None
+    hip.call('vm_layernorm_bwd', ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), rows, cols,
+             dtype_code(x.dtype), stream())
+    return dx, dw, db
+
+
+# ------------------------------------------------------------------ rope / activations / misc
+def rope_(qkv: torch.Tensor, row_pos: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_heads: int, head_dim: int,
+          inverse: bool = False, nrows: torch.Tensor | None = None):
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and cos.dtype == torch.float32 and cos.is_contiguous()
+    assert row_pos.dtype == torch.int32
+    hip.call('vm_rope_inplace', ptr(qkv), _ld(qkv), ptr(row_pos), ptr(cos), ptr(sin), cos.shape[0], qkv.shape[0],
+             n_heads, head_dim, dtype_code(qkv.dtype), int(inverse), ptr(nrows), stream())
+    return qkv
+
+
+def silu_mul(gate, up):
+    gate, up = _c(gate), _c(up)
+    out = torch.empty_like(gate)
+    hip.call('vm_silu_mul_fwd', ptr(gate), ptr(up), ptr(out), gate.numel(), dtype_code(gate.dtype), stream())
+    return out
+
+
+def silu_mul_bwd(gate, up, dout):
+    gate, up, dout = _c(gate), _c(up), _c(dout)
+    dg, du = torch.empty_like(gate), torch.empty_like(up)
+    hip.call('vm_silu_mul_bwd', ptr(gate), ptr(up), ptr(dout), ptr(dg), ptr(du), gate.numel(), dtype_code(gate.dtype), stream())
+    return dg, du
+
+
+def gelu(x):
+    x = _c(x)
+    y = torch.empty_like(x)
+    hip.call('vm_gelu_fwd', ptr(x), ptr(y), x.numel(), dtype_code(x.dtype), stream())
+    return y
+
+
+def gelu_bwd(x, dy):
+    x, dy = _c(x), _c(dy)
+    dx = torch.empty_like(x)
+    hip.call('vm_gelu_bwd', ptr(x), ptr(dy), ptr(dx), x.numel(), dtype_code(x.dtype), stream())
+    return dx
+
+
+def relu_bwd(y, dy):
+    y, dy = _c(y), _c(dy)
+    dx = torch.empty_like(y)
+    hip.call('vm_relu_bwd', ptr(y), ptr(dy), ptr(dx), y.numel(), dtype_code(y.dtype), stream())
+    return dx
+
+
+def dropout(x, p: float, seed: int):
+    x = _c(x)
+    y = torch.empty_like(x)
+    hip.call('vm_dropout', ptr(x), ptr(y), x.numel(), p, seed & 0xFFFFFFFFFFFFFFFF, dtype_code(x.dtype), stream())
+    return y
+
+
+def add(a, b):
+    a, b = _c(a), _c(b)
+    y = torch.empty_like(a)
+    hip.call('vm_add', ptr(a), ptr(b), ptr(y), a.numel(), dtype_code(a.dtype), stream())
+    return y
+
+
+def cast(x, dtype: torch.dtype):
+    x = _c(x)
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    hip.call('vm_cast', ptr(x), dtype_code(x.dtype), ptr(y), dtype_code(dtype), x.numel(), stream())
+    return y
+
+
+def gather_rows(src, idx, rows: int | None = None, nrows: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
+    rows = idx.numel() if rows is None else rows
+    if out is None:
+        out = torch.empty(rows, src.shape[1], dtype=src.dtype, device=src.device)
+    hip.call('vm_gather_rows', ptr(src), _ld(src), ptr(idx), ptr(out), _ld(out), rows, src.shape[1], dtype_code(src.dtype),
+             ptr(nrows), stream())
+    return out
+
+
+def scatter_rows(src, idx, out, rows: int | None = None, nrows: torch.Tensor | None = None):
+    assert src.dim() == 2 and src.stride(1) == 1 and idx.dtype == torch.int32
+    rows = min(idx.numel(), src.shape[0]) if rows is None else rows
+    hip.call('vm_scatter_rows', ptr(src), _ld(src), ptr(idx), ptr(out), _ld(out), rows, src.shape[1], dtype_code(src.dtype),
+             ptr(nrows), stream())
+    return out
+
+
+def embedding_bwd(dout, ids: torch.Tensor, rows: torch.Tensor, dweight: torch.Tensor):
+    """dweight[id] = sum of dout[row] over entries with that id (ids < 0 ignored). dweight must be pre-zeroed."""
+    order = torch.argsort(ids.to(torch.int64), stable=True)
+    sorted_ids = ids[order].to(torch.int32).contiguous()
+    sorted_rows = rows[order].to(torch.int32).contiguous()
+    hip.call('vm_embedding_bwd', ptr(dout), _ld(dout), ptr(sorted_ids), ptr(sorted_rows), sorted_ids.numel(), ptr(dweight),
+             _ld(dweight), dout.shape[1], dtype_code(dout.dtype), stream())
+    return dweight
+
+
+def ce_fwd(logits, labels, vocab: int, nrows: torch.Tensor | None = None):
+    rows = logits.shape[0]
+    row_loss = torch.zeros(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.zeros(rows, dtype=torch.float32, device=logits.device)
+    hip.call('vm_ce_fwd', ptr(logits), _ld(logits), ptr(labels), ptr(row_loss), ptr(lse), rows, vocab, dtype_code(logits.dtype),
+             ptr(nrows), stream())
+    return row_loss, lse
+
+
+def ce_bwd(logits, labels, lse, row_scale, vocab: int, nrows: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    rows = logits.shape[0]
+    if out is None:
+        out = torch.empty_like(logits)
+    hip.call('vm_ce_bwd', ptr(logits), _ld(logits), ptr(labels), ptr(lse), ptr(row_scale), ptr(out), _ld(out), rows, vocab,
+             dtype_code(logits.dtype), ptr(nrows), stream())
+    return out
+
+
+def im2col3d(image: torch.Tensor, patch: tuple[int, int, int], pad_k_to: int = 1):
+    image = _c(image)
+    Cc, D, H, W = image.shape
+    pz, py, px = patch
+    n = (D // pz) * (H // py) * (W // px)
+    K = Cc * pz * py * px
+    Kp = (K + pad_k_to - 1) // pad_k_to * pad_k_to
+    cols = torch.empty(n, Kp, dtype=image.dtype, device=image.device)
+    if Kp > K:
+        cols[:, K:].zero_()
+    hip.call('vm_im2col3d', ptr(image), Cc, D, H, W, pz, py, px, ptr(cols), Kp, dtype_code(image.dtype), stream())
+    return cols
+
+
+def expert_index_build(token_type_ids: torch.Tensor, attention_mask: torch.Tensor):
+    B, L = token_type_ids.shape
+    dev = token_type_ids.device
+    tt = _c(token_type_ids.to(torch.int64))
+    am = _c(attention_mask.to(torch.int64))
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    row_of_tok = torch.empty(B * L, dtype=torch.int32, device=dev)
+    tok_of_row = torch.empty(B * L, dtype=torch.int32, device=dev)
+    cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    row_of_pos = torch.empty(B * L, dtype=torch.int32, device=dev)
+    mask = torch.empty(B * L, dtype=torch.uint8, device=dev)
+    hip.call('vm_expert_index_build', ptr(tt), ptr(am), B, L, ptr(counts), ptr(row_of_tok), ptr(tok_of_row), ptr(cu),
+             ptr(row_of_pos), ptr(mask), stream())
+    return dict(counts=counts, row_of_tok=row_of_tok, tok_of_row=tok_of_row, cu_seqlens=cu, row_of_pos=row_of_pos,
+                expert_mask=mask.view(B, L))
+
+
+# ------------------------------------------------------------------ attention (bf16, var-len)
+def _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max):
+    a = hip.AttnArgs()
+    a.q, a.k, a.v, a.out = ptr(q), ptr(k), ptr(v), ptr(out)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.lse = ptr(lse)
+    a.cu_seqlens, a.n_seq = ptr(cu_seqlens), cu_seqlens.numel() - 1
+    a.row_of_pos = ptr(row_of_pos)
+    a.total_pos_max = total_pos_max
+    a.max_seqlen = max_seqlen
+    a.n_heads, a.head_dim = n_heads, head_dim
+    a.scale = scale
+    a.causal = int(causal)
+    return a
+
+
+def attn_fwd(q, k, v, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, causal: bool,
+             row_of_pos: torch.Tensor | None = None, total_pos_max: int | None = None):
+    """q,k,v: [rows, n_heads*head_dim] views (unit inner stride; may alias one qkv buffer)."""
+    assert q.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    rows = q.shape[0]
+    total_pos_max = rows if total_pos_max is None else total_pos_max
+    out = torch.zeros(rows, n_heads * head_dim, dtype=q.dtype, device=q.device)
+    lse = torch.zeros(n_heads, total_pos_max, dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max)
+    hip.call('vm_attn_fwd_bf16', C.addressof(a), stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal,
+             row_of_pos: torch.Tensor | None = None, total_pos_max: int | None = None):
+    rows = q.shape[0]
+    total_pos_max = rows if total_pos_max is None else total_pos_max
+    dout = _c(dout)
+    dqkv = torch.zeros(rows, 3, n_heads * head_dim, dtype=q.dtype, device=q.device)
+    dq, dk, dv = dqkv[:, 0], dqkv[:, 1], dqkv[:, 2]
+    delta = torch.empty(n_heads, total_pos_max, dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max)
+    a.dout, a.lddo = ptr(dout), dout.stride(0)
+    a.dq, a.dk, a.dv = ptr(dq), ptr(dk), ptr(dv)
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.delta = ptr(delta)
+    hip.call('vm_attn_bwd_bf16', C.addressof(a), stream())
+    return dqkv
+
+
+# ------------------------------------------------------------------ profiling helpers
+def prof_enable(on: bool):
+    hip.call('vm_prof_enable', int(on))
+
+
+def prof_reset():
+    hip.call('vm_prof_reset')
+
+
+def prof_collect(kind: int):
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    hip.call('vm_prof_collect', kind, C.addressof(ms), C.addressof(fl), C.addressof(n))
+    return ms.value, fl.value, n.value

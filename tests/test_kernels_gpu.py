@@ -1,0 +1,416 @@
+"""Kernel-level numerics: every HIP entry point against a plain PyTorch fp32 reference of the same op.
+
+Tolerances: fp32 kernels 1e-5 relative (fp32 accumulation order differs), bf16 kernels are compared
+after rounding the fp32 reference to bf16 the way torch would (2^-8 relative per element)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def max_err(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+@pytest.fixture(scope='module')
+def K():
+    from mmmm_amd import kernels
+    return kernels
+
+
+def test_arch(dev):
+    import ctypes
+    from mmmm_amd import hip
+    buf = ctypes.create_string_buffer(64)
+    hip.call('vm_device_arch', ctypes.addressof(buf), 64)
+    assert buf.value.decode().startswith('gfx950')
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K_', [(128, 128, 64), (256, 384, 512), (200, 136, 192), (1, 8, 64), (777, 1000, 4096), (3648, 1792, 1792)])
+def test_gemm_bf16_plain(dev, K, M, N, K_):
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N)
+    a = torch.randn(M, K_, generator=g).to(dev).bfloat16()
+    w = (torch.randn(N, K_, generator=g) / math.sqrt(K_)).to(dev).bfloat16()
+    out = K.gemm(a, w)
+    ref = (a.float() @ w.float().T)
+    assert rel_err(out, ref) < 4e-3
+    assert max_err(out, ref.bfloat16()) <= 2 ** -6 * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_bf16_asymmetric_identity(dev, K):
+    # A = I check with an asymmetric B: catches row/col swaps in the C write
+    n = 128
+    a = torch.eye(n, device=dev).bfloat16()
+    w = torch.arange(n * n, device=dev, dtype=torch.float32).view(n, n).remainder(251).bfloat16()
+    out = K.gemm(a, w)
+    assert torch.equal(out.float(), w.float().T)
+
+
+def test_gemm_bf16_f32_out_bias_act_residual(dev, K):
+    M, N, K_ = 300, 264, 256
+    a = torch.randn(M, K_, device=dev).bfloat16()
+    w = (torch.randn(N, K_, device=dev) / 16).bfloat16()
+    bias = torch.randn(N, device=dev).bfloat16()
+    res = torch.randn(M, N, device=dev).bfloat16()
+    from mmmm_amd import hip
+    out = K.gemm(a, w, bias=bias, residual=res, act=hip.ACT_GELU)
+    lin = (a.float() @ w.float().T + bias.float()).bfloat16().float()
+    ref = (torch.nn.functional.gelu(lin).bfloat16().float() + res.float())
+    assert rel_err(out, ref) < 4e-3
+    out32 = K.gemm(a, w, out_dtype=torch.float32, bias=bias.float(), act=hip.ACT_RELU)
+    ref32 = torch.relu(a.float() @ w.float().T + bias.float())
+    assert rel_err(out32, ref32) < 1e-5
+
+
+def test_gemm_bf16_lora_extension(dev, K):
+    M, N, K_, r = 260, 384, 512, 64
+    a = torch.randn(M, K_, device=dev).bfloat16()
+    w = (torch.randn(N, K_, device=dev) / 20).bfloat16()
+    t = torch.randn(M, r, device=dev).bfloat16()
+    b = (torch.randn(N, r, device=dev) / 8).bfloat16()
+    out = K.gemm(a, w, a2=t, b2=b, alpha2=0.5)
+    ref = a.float() @ w.float().T + 0.5 * (t.float() @ b.float().T)
+    assert rel_err(out, ref) < 4e-3
+
+
+def test_gemm_bf16_lora_extension_dropout_mask(dev, K):
+    # extension accumulator masked by the same (seed, index) hash as vm_dropout
+    M, N, r = 130, 256, 64
+    a = torch.zeros(M, 64, device=dev).bfloat16()
+    w = torch.zeros(N, 64, device=dev).bfloat16()
+    t = torch.randn(M, r, device=dev).bfloat16()
+    b = torch.randn(N, r, device=dev).bfloat16()
+    p, seed = 0.25, 1234567
+    out = K.gemm(a, w, a2=t, b2=b, drop_p=p, drop_seed=seed, out_dtype=torch.float32)
+    ones = torch.ones(M, N, device=dev)
+    mask = K.dropout(ones, p, seed)           # keep/(1-p) pattern of element (m, n)
+    ref = (t.float() @ b.float().T) * mask
+    assert rel_err(out, ref) < 1e-5
+    frac = (mask == 0).float().mean().item()
+    assert abs(frac - p) < 0.02
+
+
+@pytest.mark.parametrize('split', [0, 1, 100, 128, 300, 517])
+def test_gemm_bf16_two_expert_segments(dev, K, split):
+    M, N, K_ = 517, 320, 256
+    a = torch.randn(M, K_, device=dev).bfloat16()
+    w0 = (torch.randn(N, K_, device=dev) / 16).bfloat16()
+    w1 = (torch.randn(N, K_, device=dev) / 16).bfloat16()
+    ref = torch.cat([a[:split].float() @ w0.float().T, a[split:].float() @ w1.float().T])
+    out = K.gemm(a, w0, w1=w1, split=split)
+    assert rel_err(out, ref) < 4e-3
+    # device-side counts with a larger upper bound: rows past counts[1] must stay untouched
+    Mmax = 640
+    a_big = torch.zeros(Mmax, K_, device=dev).bfloat16()
+    a_big[:M] = a
+    counts = torch.tensor([split, M, 0, 0], dtype=torch.int32, device=dev)
+    out_big = torch.full((Mmax, N), 7.0, device=dev).bfloat16()
+    K.gemm(a_big, w0, w1=w1, counts=counts, out=out_big)
+    assert rel_err(out_big[:M], ref) < 4e-3
+    assert torch.all(out_big[M:] == 7.0)
+
+
+@pytest.mark.parametrize('M,N,K_', [(128, 128, 32), (300, 200, 768), (9, 768, 768), (784, 3072, 768)])
+def test_gemm_f32(dev, K, M, N, K_):
+    a = torch.randn(M, K_, device=dev)
+    w = torch.randn(N, K_, device=dev) / math.sqrt(K_)
+    bias = torch.randn(N, device=dev)
+    out = K.gemm(a, w, bias=bias)
+    ref = (a.double() @ w.double().T + bias.double()).float()
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_transpose(dev, K):
+    for dt in (torch.bfloat16, torch.float32):
+        x = torch.randn(130, 200, device=dev).to(dt)
+        y = K.transpose(x, pad_to=64)
+        assert y.shape == (200, 192)
+        assert torch.equal(y[:, :130], x.T)
+        assert torch.all(y[:, 130:] == 0)
+        n = torch.tensor([100], dtype=torch.int32, device=dev)
+        y = K.transpose(x, pad_to=64, nrows=n)
+        assert torch.equal(y[:, :100], x[:100].T) and torch.all(y[:, 100:] == 0)
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('cols', [64, 4096])
+def test_rmsnorm(dev, K, dt, cols):
+    rows, eps = 77, 1e-6
+    x = torch.randn(rows, cols, device=dev).to(dt).requires_grad_()
+    w = (1 + 0.1 * torch.randn(cols, device=dev)).to(dt).requires_grad_()
+    xf, wf = x.detach().float().requires_grad_(), w.detach().float().requires_grad_()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    ref = wf * (xf * torch.rsqrt(var + eps))
+    dy = torch.randn(rows, cols, device=dev).to(dt)
+    ref.backward(dy.float())
+    y, rstd = K.rmsnorm_fwd(x.detach(), w.detach(), eps)
+    tol = 5e-3 if dt == torch.bfloat16 else 1e-5
+    assert rel_err(y, ref) < tol
+    dx, dw = K.rmsnorm_bwd(x.detach(), w.detach(), dy, rstd)
+    assert rel_err(dx, xf.grad) < tol
+    assert rel_err(dw, wf.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('cols', [192, 768, 1792])
+def test_layernorm(dev, K, dt, cols):
+    rows, eps = 133, 1e-6
+    x = torch.randn(rows, cols, device=dev).to(dt)
+    w = (1 + 0.1 * torch.randn(cols, device=dev)).to(dt)
+    b = (0.1 * torch.randn(cols, device=dev)).to(dt)
+    res = torch.randn(rows, cols, device=dev).to(dt)
+    xf, wf, bf = (t.float().requires_grad_() for t in (x, w, b))
+    ref = torch.nn.functional.layer_norm(xf, (cols,), wf, bf, eps)
+    dy = torch.randn(rows, cols, device=dev).to(dt)
+    ref.backward(dy.float())
+    y, mean, rstd = K.layernorm_fwd(x, w, b, eps)
+    tol = 5e-3 if dt == torch.bfloat16 else 1e-5
+    assert rel_err(y, ref) < tol
+    y2, _, _ = K.layernorm_fwd(x, w, b, eps, residual=res)
+    assert rel_err(y2, ref.detach().to(dt).float() + res.float()) < tol
+    dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd)
+    assert rel_err(dx, xf.grad) < tol
+    assert rel_err(dw, wf.grad) < 1e-4 and rel_err(db, bf.grad) < 1e-4
+
+
+# ------------------------------------------------------------------ rope
+def _rope_ref(q, k, cos, sin, pos):
+    def rot(x):
+        x1, x2 = x[..., :x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return torch.cat((-x2, x1), dim=-1)
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    return q * c + rot(q) * s, k * c + rot(k) * s
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_rope(dev, K, dt):
+    rows, H, hd, npos = 50, 4, 128, 40
+    qkv = torch.randn(rows, 3 * H * hd, device=dev).to(dt)
+    pos = torch.randint(0, npos, (rows,), device=dev, dtype=torch.int32)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    fr = torch.outer(torch.arange(npos, device=dev).float(), inv)
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos().contiguous(), emb.sin().contiguous()
+    q = qkv[:, :H * hd].float().view(rows, H, hd)
+    k = qkv[:, H * hd:2 * H * hd].float().view(rows, H, hd)
+    qr, kr = _rope_ref(q, k, cos, sin, pos.long())
+    work = qkv.clone()
+    K.rope_(work, pos, cos, sin, H, hd)
+    tol = 5e-3 if dt == torch.bfloat16 else 1e-6
+    assert rel_err(work[:, :H * hd].view(rows, H, hd), qr) < tol
+    assert rel_err(work[:, H * hd:2 * H * hd].view(rows, H, hd), kr) < tol
+    assert torch.equal(work[:, 2 * H * hd:], qkv[:, 2 * H * hd:])
+    # inverse is the transpose of the rotation: <R x, y> == <x, R^T y>
+    if dt == torch.float32:
+        y = torch.randn_like(qkv)
+        ry = y.clone()
+        K.rope_(ry, pos, cos, sin, H, hd, inverse=True)
+        lhs = (work[:, :2 * H * hd] * y[:, :2 * H * hd]).sum()
+        rhs = (qkv[:, :2 * H * hd] * ry[:, :2 * H * hd]).sum()
+        assert abs(lhs - rhs) / abs(lhs) < 1e-4
+
+
+# ------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_activations(dev, K, dt):
+    n = 8 * 1000 + 3
+    g = torch.randn(n, device=dev).to(dt)
+    u = torch.randn(n, device=dev).to(dt)
+    d = torch.randn(n, device=dev).to(dt)
+    gf, uf = g.float().requires_grad_(), u.float().requires_grad_()
+    ref = torch.nn.functional.silu(gf) * uf
+    ref.backward(d.float())
+    tol = 5e-3 if dt == torch.bfloat16 else 1e-6
+    assert rel_err(K.silu_mul(g, u), ref) < tol
+    dg, du = K.silu_mul_bwd(g, u, d)
+    assert rel_err(dg, gf.grad) < tol and rel_err(du, uf.grad) < tol
+    xf = g.float().requires_grad_()
+    r2 = torch.nn.functional.gelu(xf)
+    r2.backward(d.float())
+    assert rel_err(K.gelu(g), r2) < tol
+    assert rel_err(K.gelu_bwd(g, d), xf.grad) < tol
+    y = torch.relu(g)
+    assert rel_err(K.relu_bwd(y, d), torch.where(y > 0, d, torch.zeros_like(d))) < 1e-6
+    assert rel_err(K.add(g, u), (g.float() + u.float()).to(dt)) < 1e-6
+
+
+def test_dropout_is_deterministic_and_unbiased(dev, K):
+    x = torch.ones(1 << 20, device=dev).bfloat16()
+    a = K.dropout(x, 0.05, 42)
+    b = K.dropout(x, 0.05, 42)
+    c = K.dropout(x, 0.05, 43)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs((a == 0).float().mean().item() - 0.05) < 2e-3
+    assert abs(a.float().mean().item() - 1.0) < 5e-3
+
+
+def test_gather_scatter_cast(dev, K):
+    src = torch.randn(40, 64, device=dev).bfloat16()
+    idx = torch.tensor([3, -1, 39, 0, 3], dtype=torch.int32, device=dev)
+    g = K.gather_rows(src, idx)
+    assert torch.equal(g[0], src[3]) and torch.all(g[1] == 0) and torch.equal(g[2], src[39]) and torch.equal(g[4], src[3])
+    out = torch.zeros(50, 64, device=dev).bfloat16()
+    sidx = torch.tensor([5, -1, 7], dtype=torch.int32, device=dev)
+    K.scatter_rows(src[:3], sidx, out)
+    assert torch.equal(out[5], src[0]) and torch.equal(out[7], src[2]) and out.float().abs().sum() == (src[0].float().abs().sum() + src[2].float().abs().sum())
+    assert torch.equal(K.cast(src, torch.float32), src.float())
+    assert torch.equal(K.cast(src.float(), torch.bfloat16), src)
+
+
+def test_embedding_bwd(dev, K):
+    V, h, n = 50, 64, 30
+    ids = torch.randint(0, 10, (n,), device=dev, dtype=torch.int32)
+    ids[4] = -1
+    rows = torch.arange(n, device=dev, dtype=torch.int32)
+    dout = torch.randn(n, h, device=dev)
+    dw = torch.zeros(V, h, device=dev)
+    K.embedding_bwd(dout, ids, rows, dw)
+    ref = torch.zeros(V, h, device=dev)
+    m = ids >= 0
+    ref.index_add_(0, ids[m].long(), dout[m])
+    assert rel_err(dw, ref) < 1e-6
+
+
+# ------------------------------------------------------------------ cross entropy
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_weighted_ce(dev, K, dt):
+    rows, vocab, ld = 37, 32008, 32064
+    buf = torch.zeros(rows, ld, device=dev).to(dt)
+    buf[:, :vocab] = (3 * torch.randn(rows, vocab, device=dev)).to(dt)
+    logits = buf[:, :vocab]
+    labels = torch.randint(0, vocab, (rows,), device=dev)
+    labels[::5] = -100
+    lf = logits.float().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(lf, labels, reduction='none')
+    row_loss, lse = K.ce_fwd(buf, labels, vocab)
+    assert rel_err(row_loss, ref) < 1e-5
+    scale = torch.rand(rows, device=dev)
+    (ref * scale).sum().backward()
+    dl = K.ce_bwd(buf, labels, lse, scale * (labels >= 0), vocab)
+    tol = 8e-3 if dt == torch.bfloat16 else 1e-5
+    assert rel_err(dl[:, :vocab], lf.grad) < tol
+    assert torch.all(dl[:, vocab:] == 0)
+
+
+# ------------------------------------------------------------------ routing metadata
+def test_expert_index_build(dev, K):
+    B, L = 3, 12
+    tt = torch.tensor([
+        [0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0],
+        [0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0],
+        [0, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1],
+    ], device=dev)
+    am = torch.ones(B, L, dtype=torch.long, device=dev)
+    am[1, 8:] = 0
+    am[2, 10:] = 0
+    r = K.expert_index_build(tt, am)
+    pm = am.bool()
+    vis = torch.zeros_like(pm)
+    vis[:, :-1] = (tt[:, :-1] == 1) & (tt[:, 1:] == 1)
+    lang = ~vis
+    vis &= pm
+    lang &= pm
+    mask = r['expert_mask']
+    assert torch.equal((mask & 1).bool(), vis) and torch.equal((mask & 2).bool(), lang)
+    counts = r['counts'].tolist()
+    assert counts[0] == int(vis.sum()) and counts[1] == int(pm.sum()) and counts[2] == int(pm.sum(1).max())
+    assert r['cu_seqlens'].tolist() == [0, 12, 20, 30]
+    rot = r['row_of_tok'].view(B, L)
+    assert torch.all(rot[~pm] == -1)
+    assert sorted(rot[pm].tolist()) == list(range(counts[1]))
+    assert torch.all(rot[vis] < counts[0]) and torch.all(rot[lang] >= counts[0])
+    # order preserved inside each segment
+    assert rot[vis].tolist() == sorted(rot[vis].tolist()) and rot[lang].tolist() == sorted(rot[lang].tolist())
+    tor = r['tok_of_row']
+    flat = rot.flatten()
+    for t in range(B * L):
+        if flat[t] >= 0:
+            assert tor[flat[t]] == t
+    assert r['row_of_pos'][:counts[1]].tolist() == rot[pm].tolist()
+
+
+# ------------------------------------------------------------------ im2col
+def test_im2col(dev, K):
+    img = torch.randn(3, 4, 32, 48, device=dev)
+    cols = K.im2col3d(img, (2, 16, 16))
+    w = torch.randn(5, 3, 2, 16, 16, device=dev)
+    ref = torch.nn.functional.conv3d(img[None], w, stride=(2, 16, 16))[0]  # [5, 2, 2, 3]
+    out = cols @ w.flatten(1).T
+    assert rel_err(out.T.reshape(ref.shape), ref) < 1e-5
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, cu, scale, causal):
+    """q,k,v: [rows, H, hd] fp32; block-diagonal (causal) attention"""
+    out = torch.zeros_like(q)
+    for i in range(len(cu) - 1):
+        s, e = cu[i], cu[i + 1]
+        qi, ki, vi = (t[s:e].transpose(0, 1) for t in (q, k, v))
+        sc = qi @ ki.transpose(1, 2) * scale
+        if causal:
+            L = e - s
+            sc = sc.masked_fill(torch.ones(L, L, device=q.device).triu(1).bool(), float('-inf'))
+        out[s:e] = (sc.softmax(-1) @ vi).transpose(0, 1)
+    return out
+
+
+@pytest.mark.parametrize('hd,H,causal', [(128, 2, True), (112, 3, False), (128, 1, False), (64, 2, True)])
+@pytest.mark.parametrize('lens', [[130], [64, 1, 200], [456, 456], [785]])
+def test_attention_bf16(dev, K, hd, H, causal, lens):
+    cu = [0]
+    for l in lens:
+        cu.append(cu[-1] + l)
+    rows = cu[-1]
+    qkv = torch.randn(rows, 3, H, hd, device=dev).bfloat16()
+    q, k, v = (qkv[:, i].reshape(rows, H * hd) for i in range(3))
+    qkv2 = qkv.view(rows, 3 * H * hd)
+    qv, kv, vv = qkv2[:, :H * hd], qkv2[:, H * hd:2 * H * hd], qkv2[:, 2 * H * hd:]
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=dev)
+    scale = hd ** -0.5
+    out, lse = K.attn_fwd(qv, kv, vv, cu_t, max(lens), H, hd, scale, causal)
+    qf, kf, vf = (t.float().view(rows, H, hd).requires_grad_() for t in (q, k, v))
+    ref = _attn_ref(qf, kf, vf, cu, scale, causal)
+    assert rel_err(out.view(rows, H, hd), ref) < 1e-2
+    dout = torch.randn(rows, H * hd, device=dev).bfloat16()
+    ref.backward(dout.float().view(rows, H, hd))
+    dqkv = K.attn_bwd(qv, kv, vv, out, lse, dout, cu_t, max(lens), H, hd, scale, causal)
+    assert rel_err(dqkv[:, 0].view(rows, H, hd), qf.grad) < 2e-2
+    assert rel_err(dqkv[:, 1].view(rows, H, hd), kf.grad) < 2e-2
+    assert rel_err(dqkv[:, 2].view(rows, H, hd), vf.grad) < 2e-2
+
+
+def test_attention_bf16_row_indirection(dev, K):
+    # expert-sorted physical rows: sequence position -> row through row_of_pos
+    H, hd, lens = 2, 128, [70, 90]
+    rows = sum(lens)
+    perm = torch.randperm(rows, device=dev)
+    qkv_seq = torch.randn(rows, 3 * H * hd, device=dev).bfloat16()
+    qkv_phys = torch.empty_like(qkv_seq)
+    qkv_phys[perm] = qkv_seq           # position i lives at row perm[i]
+    cu_t = torch.tensor([0, 70, 160], dtype=torch.int32, device=dev)
+    sl = lambda t: (t[:, :H * hd], t[:, H * hd:2 * H * hd], t[:, 2 * H * hd:])
+    o_seq, _ = K.attn_fwd(*sl(qkv_seq), cu_t, 90, H, hd, hd ** -0.5, True)
+    o_phys, _ = K.attn_fwd(*sl(qkv_phys), cu_t, 90, H, hd, hd ** -0.5, True, row_of_pos=perm.int())
+    assert torch.equal(o_phys[perm], o_seq)
+
+
+def test_attention_rare_rescale_branch(dev, K):
+    # spike one key late in the sequence so the running max jumps in a later tile (guide rule 26)
+    H, hd, L = 1, 128, 256
+    q = torch.randn(L, H * hd, device=dev).bfloat16() * 0.1
+    k = torch.randn(L, H * hd, device=dev).bfloat16() * 0.1
+    v = torch.randn(L, H * hd, device=dev).bfloat16()
+    k[200] = (q[30].float() * 60).bfloat16()
+    cu_t = torch.tensor([0, L], dtype=torch.int32, device=dev)
+    out, _ = K.attn_fwd(q, k, v, cu_t, L, H, hd, 1.0, False)
+    ref = _attn_ref(q.float().view(L, H, hd), k.float().view(L, H, hd), v.float().view(L, H, hd), [0, L], 1.0, False)
+    assert rel_err(out.view(L, H, hd), ref) < 1e-2
