@@ -168,7 +168,7 @@ def test_layernorm(dev, K, dt, cols):
     w = (1 + 0.1 * torch.randn(cols, device=dev)).to(dt)
     b = (0.1 * torch.randn(cols, device=dev)).to(dt)
     res = torch.randn(rows, cols, device=dev).to(dt)
-    xf, wf, bf = (t.float().requires_grad_() for t in (x, w, b))
+    xf, wf, bf = (t.float().clone().requires_grad_() for t in (x, w, b))
     ref = torch.nn.functional.layer_norm(xf, (cols,), wf, bf, eps)
     dy = torch.randn(rows, cols, device=dev).to(dt)
     ref.backward(dy.float())
@@ -226,14 +226,14 @@ def test_activations(dev, K, dt):
     g = torch.randn(n, device=dev).to(dt)
     u = torch.randn(n, device=dev).to(dt)
     d = torch.randn(n, device=dev).to(dt)
-    gf, uf = g.float().requires_grad_(), u.float().requires_grad_()
+    gf, uf = g.float().clone().requires_grad_(), u.float().clone().requires_grad_()
     ref = torch.nn.functional.silu(gf) * uf
     ref.backward(d.float())
     tol = 5e-3 if dt == torch.bfloat16 else 1e-6
     assert rel_err(K.silu_mul(g, u), ref) < tol
     dg, du = K.silu_mul_bwd(g, u, d)
     assert rel_err(dg, gf.grad) < tol and rel_err(du, uf.grad) < tol
-    xf = g.float().requires_grad_()
+    xf = g.float().clone().requires_grad_()
     r2 = torch.nn.functional.gelu(xf)
     r2.backward(d.float())
     assert rel_err(K.gelu(g), r2) < tol
@@ -289,7 +289,7 @@ def test_weighted_ce(dev, K, dt):
     logits = buf[:, :vocab]
     labels = torch.randint(0, vocab, (rows,), device=dev)
     labels[::5] = -100
-    lf = logits.float().requires_grad_()
+    lf = logits.float().clone().requires_grad_()
     ref = torch.nn.functional.cross_entropy(lf, labels, reduction='none')
     row_loss, lse = K.ce_fwd(buf, labels, vocab)
     assert rel_err(row_loss, ref) < 1e-5
@@ -377,7 +377,7 @@ def test_attention_bf16(dev, K, hd, H, causal, lens):
     cu_t = torch.tensor(cu, dtype=torch.int32, device=dev)
     scale = hd ** -0.5
     out, lse = K.attn_fwd(qv, kv, vv, cu_t, max(lens), H, hd, scale, causal)
-    qf, kf, vf = (t.float().view(rows, H, hd).requires_grad_() for t in (q, k, v))
+    qf, kf, vf = (t.float().view(rows, H, hd).clone().requires_grad_() for t in (q, k, v))
     ref = _attn_ref(qf, kf, vf, cu, scale, causal)
     assert rel_err(out.view(rows, H, hd), ref) < 1e-2
     dout = torch.randn(rows, H * hd, device=dev).bfloat16()
