@@ -1,0 +1,326 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.pt by running the REFERENCE (imported from
+/root/reference through oracle/ref_shims.py) on explicit tensors. Runs only in the development container:
+
+    python -m oracle.make_golden
+
+Fixtures hold inputs, explicit weights and the reference's outputs (data only, no reference source).
+"""
+from __future__ import annotations
+
+import math
+import os
+from pathlib import Path
+import types
+
+import torch
+
+from . import ref_shims
+
+OUT = Path(__file__).resolve().parents[1] / 'tests' / 'golden'
+
+
+def randomize_(module: torch.nn.Module, seed: int):
+    """explicit, non-degenerate values for every parameter/buffer (norm weights near 1, nothing at zero)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            leaf = name.rsplit('.', 1)[-1]
+            if p.ndim == 1 and ('norm' in name or 'layernorm' in name or name.endswith('output_upscaling.1.weight')) and leaf == 'weight':
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif leaf == 'bias':
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p.shape[1] if p.ndim >= 2 else p.shape[0]
+                if p.ndim > 2:
+                    fan_in = math.prod(p.shape[1:])
+                std = 0.5 if p.ndim < 2 or 'embed' in name or name.endswith(('boi', 'eoi')) else 1.0 / math.sqrt(fan_in)
+                p.copy_(std * torch.randn(p.shape, generator=g))
+        for name, b in module.named_buffers():
+            if 'positional_encoding_gaussian_matrix' in name:
+                b.copy_(torch.randn(b.shape, generator=g))
+
+
+def tiny_cfg(R, n_lm=2, n_vit=2):
+    cfg = R.config.CogVLMConfig(
+        vocab_size=160, hidden_size=64, intermediate_size=128, num_hidden_layers=n_lm, num_attention_heads=2,
+        vision_config=dict(in_channels=3, hidden_size=32, patch_size=(4, 8, 8), num_heads=2, num_hidden_layers=n_vit,
+                           intermediate_size=64, hidden_act='gelu', dropout_prob=0.0, layer_norm_eps=1e-6,
+                           pos_embed_shape=(2, 2, 4), pt_pos_embed_shape=(2, 4)),
+    )
+    va = R.mmmm.VisionArgs(pos_embed_shape=(2, 2, 4), pt_pos_embed_shape=(2, 4), patch_size=(4, 8, 8))
+    return cfg, va
+
+
+def make_vlm_inputs(samples, L, g):
+    """samples: list of (n_image_tokens Np, n_text T). Returns right-padded reference-style inputs
+    (layout of mmmm/data/utils.py:104-140)."""
+    B = len(samples)
+    ids = torch.zeros(B, L, dtype=torch.long)
+    tt = torch.zeros(B, L, dtype=torch.long)
+    pos = torch.zeros(B, L, dtype=torch.long)
+    am = torch.zeros(B, L, dtype=torch.long)
+    labels = torch.full((B, L), -100, dtype=torch.long)
+    weight = torch.zeros(B, L)
+    BOP, EOP, GRD = 150, 151, 152
+    for b, (Np, T) in enumerate(samples):
+        n = 1 + (Np + 2) + 1 + T
+        text = torch.randint(3, 140, (T,), generator=g)
+        # two <p> ... </p> pairs
+        text[3], text[6], text[10], text[14] = BOP, EOP, BOP, EOP
+        ids[b, :n] = torch.cat([torch.tensor([1]), torch.zeros(Np + 2, dtype=torch.long), torch.tensor([GRD]), text])
+        tt[b, 1:1 + Np + 2] = 1
+        tp = torch.empty(T, dtype=torch.long)
+        tp[0] = 5
+        for i in range(1, T):
+            tp[i] = tp[i - 1] if (text[i - 1] == BOP or text[i] == EOP) else tp[i - 1] + 1
+        pos[b, :n] = torch.cat([torch.tensor([0, 1]), torch.full((Np,), 2), torch.tensor([3, 4]), tp])
+        am[b, :n] = 1
+        lab = torch.cat([text[1:], torch.tensor([2])])
+        labels[b, n - T:n] = lab
+        weight[b, n - T:n] = 1.0
+        weight[b, n - T:n][lab == BOP] = 5.0
+    return dict(input_ids=ids, token_type_ids=tt, position_ids=pos, attention_mask=am, labels=labels, weight=weight)
+
+
+def f1_masks(R):
+    g = torch.Generator().manual_seed(1)
+    cases = []
+    pats = [
+        ([0, 1, 1, 1, 1, 0, 0, 0, 0, 0], [1] * 10),
+        ([0, 1, 1, 1, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1, 0, 0, 0]),
+        ([1, 1, 1, 0, 0, 1, 1, 0, 1, 1], [1] * 10),
+        ([0, 0, 0, 0, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 0, 0, 0, 0, 0, 0]),
+        ([1], [1]),
+    ]
+    for tt, am in pats:
+        tt_t, am_t = torch.tensor([tt]), torch.tensor([am])
+        v, l = R.modeling_cogvlm.get_expert_mask(tt_t, am_t.bool())
+        p = R.modeling_cogvlm.build_position_ids(tt_t, am_t)
+        cases.append(dict(token_type_ids=tt_t, attention_mask=am_t, vision=v, language=l, position_ids=p))
+    tt = torch.randint(0, 2, (4, 33), generator=g)
+    am = torch.ones(4, 33, dtype=torch.long)
+    am[1, 20:] = 0
+    am[3, 5:] = 0
+    v, l = R.modeling_cogvlm.get_expert_mask(tt, am.bool())
+    cases.append(dict(token_type_ids=tt, attention_mask=am, vision=v, language=l, position_ids=R.modeling_cogvlm.build_position_ids(tt, am)))
+    torch.save(cases, OUT / 'f1_expert_mask.pt')
+
+
+def f3_units(R):
+    g = torch.Generator().manual_seed(3)
+    mc = R.modeling_cogvlm
+    x = torch.randn(5, 64, generator=g)
+    norm = mc.RMSNorm(64, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(64, generator=g))
+    rot = mc.RotaryEmbedding(32)
+    q, k = torch.randn(2, 2, 7, 32, generator=g), torch.randn(2, 2, 7, 32, generator=g)
+    pos = torch.tensor([[0, 1, 2, 2, 2, 3, 4], [0, 1, 2, 3, 3, 4, 9]])
+    cos, sin = rot(q, seq_len=int(pos.max()) + 1)
+    qr, kr = mc.apply_rotary_pos_emb_index_bhs(q, k, cos, sin, pos)
+    logits = torch.randn(3, 6, 50, generator=g)
+    labels = torch.randint(0, 50, (3, 6), generator=g)
+    labels[0, :2] = -100
+    w = torch.rand(3, 6, generator=g) * 5
+    # bf16 rope table quirk: module converted to bf16 -> inv_freq bf16
+    rot16 = mc.RotaryEmbedding(32).to(torch.bfloat16)
+    c16, s16 = rot16(q.bfloat16(), seq_len=600)
+    torch.save(dict(
+        rms=dict(x=x, w=norm.weight.detach().clone(), y=norm(x).detach()),
+        rope=dict(q=q, k=k, pos=pos, cos=cos[:, 0].clone(), sin=sin[:, 0].clone(), q_out=qr, k_out=kr),
+        rope_bf16_table=dict(cos=c16[:, 0].float().clone(), sin=s16[:, 0].float().clone()),
+        ce=dict(logits=logits, labels=labels, weight=w, loss=mc._sample_weighted_ce(logits, labels, w)),
+    ), OUT / 'f3_units.pt')
+
+
+def build_tiny_model(R, with_sam: bool, seed: int, n_lm=2, n_vit=2):
+    cfg, va = tiny_cfg(R, n_lm, n_vit)
+    m = R.mmmm.MMMMForCausalLM(cfg, vision_override=va)
+    tok = types.SimpleNamespace(bop_token_id=150, eop_token_id=151)
+    m.tokenizer = tok
+    m.lm_loss_weight = 1.0
+    m.sam = None
+    if with_sam:
+        sam = R.build_sam._build_sam(embed_dim=32, encoder_num_layers=2, num_heads=2, patch_size=(4, 8, 8), pos_embed_shape=(2, 2, 4))
+        isam = R.build_sam._build_instance_sam(embed_dim=32, encoder_num_layers=2, num_heads=2, patch_size=(4, 8, 8),
+                                               pos_embed_shape=(2, 2, 4), num_instances=6)
+        m.sam, m.isam_model = sam, isam
+        m.mask_loss = R.loss.DiceFocalLoss(dice_weight=2, focal_weight=2, focal_gamma=2)
+        m.isam_loss = R.sam.InstanceSamLoss(use_neg_mask=False, box_l1_weight=5, box_giou_weight=2, disc_weight=2,
+                                            disc_focal_gamma=2, disc_focal_alpha=0.85)
+        m.isam_loss.mask_loss = m.mask_loss
+        m.vg_proj = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(inplace=True), torch.nn.Linear(64, 32))
+    m.trainer = types.SimpleNamespace(is_parallel=False)
+    randomize_(m, seed)
+    return m, cfg
+
+
+def f5_tiny_lm(R):
+    """tiny CogVLM (2+2 layers) forward/backward on a mixed 2D/3D right-padded batch"""
+    g = torch.Generator().manual_seed(5)
+    m, cfg = build_tiny_model(R, False, seed=50)
+    m.train()
+    images = [torch.randn(3, 1, 16, 32, generator=g), torch.randn(3, 8, 16, 32, generator=g), torch.randn(3, 4, 32, 16, generator=g)]
+    patch = [(1, 8, 8), (4, 8, 8), (2, 8, 8)]
+    pool = [(1, 2, 2), (2, 2, 2), (1, 1, 1)]
+    # tokens after pooling: (1,2,4)->(1,1,2)=2 ; (2,2,4)->(1,1,2)=2 ; (2,4,2)->16
+    vi = make_vlm_inputs([(2, 20), (2, 17), (16, 22)], L=44, g=g)
+    out = m(**vi, image=images, patch_size=patch, pool_size=pool, return_dict=True, output_hidden_states=True)
+    out.loss.backward()
+    names = ['model.layers.0.self_attn.vision_expert_query_key_value.weight', 'model.layers.1.mlp.language_mlp.down_proj.weight',
+             'model.layers.0.input_layernorm.weight', 'model.embed_tokens.weight', 'lm_head.weight',
+             'model.vision.transformer.layers.0.attention.query_key_value.weight', 'model.vision.patch_embedding.proj.weight',
+             'model.vision.patch_embedding.position_embedding.weight', 'model.vision.linear_proj.gate_proj.weight',
+             'model.vision.transformer.layers.1.post_attention_layernorm.weight', 'model.vision.patch_embedding.cls_embedding.weight']
+    params = dict(m.named_parameters())
+    am = vi['attention_mask'].bool()
+    torch.save(dict(
+        state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
+        images=images, patch_size=patch, pool_size=pool, vlm_inputs=vi,
+        logits=out.logits.detach(), loss=out.loss.detach(),
+        hidden_states=[h.detach() * am[..., None] for h in out.hidden_states],   # padded rows are undefined in the reference
+        grads={n: params[n].grad.clone() for n in names},
+        meta=dict(note='sample 0 and 2 resample the position embedding (UNPINNED luolib semantics, shim = trilinear); sample 1 is the identity case'),
+    ), OUT / 'f5_tiny_lm.pt')
+
+
+def f4_vit_identity(R):
+    """vision tower alone on an identity-resample input (pins everything except luolib.resample) + z-fold conv"""
+    g = torch.Generator().manual_seed(4)
+    m, cfg = build_tiny_model(R, False, seed=40)
+    m.eval()
+    images = [torch.randn(3, 8, 16, 32, generator=g), torch.randn(3, 4, 16, 32, generator=g)]
+    patch = [(4, 8, 8), (2, 8, 8)]        # second: kernel z 4 folded to 2 (resample.py:55-62)
+    pool = [(2, 2, 2), (1, 2, 2)]
+    with torch.no_grad():
+        feats = m.model.vision(images, patch, pool)
+        conv = m.model.vision.patch_embedding.proj(images[1][None], patch[1])
+    torch.save(dict(state_dict={k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith('model.vision')},
+                    images=images, patch_size=patch, pool_size=pool, feats=[f[0] for f in feats], conv_zfold=conv), OUT / 'f4_vit.pt')
+
+
+def f6_sam(R):
+    g = torch.Generator().manual_seed(6)
+    sam = R.build_sam._build_sam(embed_dim=32, encoder_num_layers=2, num_heads=2, patch_size=(4, 8, 8), pos_embed_shape=(2, 2, 4))
+    isam = R.build_sam._build_instance_sam(embed_dim=32, encoder_num_layers=2, num_heads=2, patch_size=(4, 8, 8),
+                                           pos_embed_shape=(2, 2, 4), num_instances=6)
+    randomize_(sam, 60)
+    randomize_(isam, 61)
+    images = [torch.rand(3, 8, 16, 32, generator=g), torch.rand(3, 1, 16, 32, generator=g), torch.rand(3, 4, 32, 16, generator=g)]
+    patch = [(4, 8, 8), (1, 8, 8), (2, 8, 8)]
+    prompts = [torch.randn(1, 32, generator=g).requires_grad_(), torch.randn(3, 32, generator=g).requires_grad_(),
+               torch.randn(2, 32, generator=g).requires_grad_()]
+    masks = sam(images, patch, prompts)
+    sum(mk.square().mean() for mk in masks).backward()
+    gp = [p.grad.clone() for p in prompts]
+    for p in prompts:
+        p.grad = None
+    out = isam(images, patch, prompts)
+    (sum(b.sum() for b in out.boxes) + sum(d.square().sum() for d in out.disc_logit) + sum(mm.mean() for mm in out.masks_logits)).backward()
+    torch.save(dict(
+        sam_state={k: v.detach().clone() for k, v in sam.state_dict().items()},
+        isam_state={k: v.detach().clone() for k, v in isam.state_dict().items()},
+        images=images, patch_size=patch, prompts=[p.detach().clone() for p in prompts],
+        sam_masks=[m_.detach() for m_ in masks], sam_prompt_grads=gp,
+        isam_masks_2d=out.masks_logits[1].detach(), isam_low=[m_.detach() for m_ in out.masks_logits_low_res],
+        isam_boxes=[b.detach() for b in out.boxes], isam_disc=[d.detach() for d in out.disc_logit],
+        isam_prompt_grads=[p.grad.clone() for p in prompts],
+        meta=dict(note='image 0 is the identity-resample case; images 1,2 resample position embeddings (UNPINNED)'),
+    ), OUT / 'f6_sam.pt')
+
+
+def f7_losses(R):
+    g = torch.Generator().manual_seed(7)
+    dfl = R.loss.DiceFocalLoss(dice_weight=2, focal_weight=2, focal_gamma=2)
+    x = torch.randn(3, 1, 4, 16, 16, generator=g) * 2
+    t = torch.rand(3, 1, 4, 16, 16, generator=g) < 0.2
+    d = dfl(x, t, return_dict=True)
+    d_nb = dfl(x, t, reduce_batch=False, return_dict=True)
+    d_none = dfl(x, None, return_dict=True)
+    il = R.sam.InstanceSamLoss(use_neg_mask=False, box_l1_weight=5, box_giou_weight=2, disc_weight=2, disc_focal_gamma=2,
+                               disc_focal_alpha=0.85)
+    il.mask_loss = dfl
+    nt, M = 3, 7
+    boxes_reg = torch.rand(nt, M, 6, generator=g) * 0.5 + 0.2
+    disc = torch.randn(nt, M - 1, generator=g)
+    boxes_label = torch.rand(9, 6, generator=g) * 0.4 + 0.3
+    index_offsets = torch.tensor([[0, 2], [2, 2], [2, 9]])     # 2 instances, none, 7 (> num queries)
+    dummy = boxes_reg.new_empty((nt, M, 0, 0, 0))
+    br = boxes_reg.clone().requires_grad_()
+    dl = disc.clone().requires_grad_()
+    loss, log = il.compute_loss(dummy, dummy, br, dl, None, boxes_label, index_offsets)
+    loss.backward()
+    # recover the assignment the reference used
+    matches = []
+    for i in range(nt):
+        s, e = index_offsets[i].tolist()
+        mt = il._match_instances(dummy[i, 1:, None], boxes_reg[i, 1:], disc[i].float(), None, boxes_label[s:e], 0, int(index_offsets[i, 0]))
+        matches.append(mt if torch.is_tensor(mt) else torch.full((M - 1,), mt))
+    torch.save(dict(
+        dice_focal=dict(x=x, t=t, out={k: v.detach() for k, v in d.items()}, out_nobatch={k: v.detach() for k, v in d_nb.items()},
+                        out_none={k: v.detach() for k, v in d_none.items()}),
+        isam=dict(boxes_reg=boxes_reg, disc=disc, boxes_label=boxes_label, index_offsets=index_offsets, loss=loss.detach(),
+                  log={k: v.detach() for k, v in log.items()}, match=torch.stack(matches), d_boxes=br.grad.clone(), d_disc=dl.grad.clone()),
+        giou=dict(a=boxes_reg[0], b=boxes_label[:7],
+                  out=ref_shims.box_pair_giou(ref_shims.convert_box_mode(boxes_reg[0], src_mode=ref_shims.CenterSizeMode),
+                                              ref_shims.convert_box_mode(boxes_label[:7], src_mode=ref_shims.CenterSizeMode))),
+    ), OUT / 'f7_losses.pt')
+
+
+def f8_training_step(R):
+    """MMMMForCausalLM.training_step with sam (mask loss) and isam (box/disc loss + Hungarian) branches live"""
+    g = torch.Generator().manual_seed(8)
+    m, cfg = build_tiny_model(R, True, seed=80)
+    m.train()
+    images = [torch.randn(3, 1, 16, 32, generator=g), torch.randn(3, 8, 16, 32, generator=g)]
+    gimages = [torch.rand(3, 1, 16, 32, generator=g), torch.rand(3, 8, 16, 32, generator=g)]
+    patch = [(1, 8, 8), (4, 8, 8)]
+    pool = [(1, 2, 2), (2, 2, 2)]
+    vi = make_vlm_inputs([(2, 20), (2, 18)], L=28, g=g)
+    masks = [torch.rand(2, 1, 16, 32, generator=g) < 0.15, None]
+    boxes = [None, torch.rand(5, 6, generator=g) * 0.4 + 0.3]
+    index_offsets = [None, torch.tensor([[0, 2], [2, 5]])]
+    batch = dict(vlm_inputs=vi, image=images, grounding_image=gimages, patch_size=patch, pool_size=pool, masks=masks, boxes=boxes,
+                 index_offsets=index_offsets, instance_mask=[False, True], vg_label_mask=[None, None])
+    loss = m.training_step(batch)
+    loss.backward()
+    params = dict(m.named_parameters())
+    names = ['vg_proj.0.weight', 'vg_proj.2.bias', 'model.layers.1.self_attn.language_expert_dense.weight', 'model.norm.weight',
+             'sam.mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight', 'sam.image_encoder.blocks.0.attn.qkv.weight',
+             'isam_model.box_head.4.weight', 'isam_model.mask_decoder.mask_tokens.weight', 'lm_head.weight']
+    torch.save(dict(
+        state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
+        batch=batch, loss=loss.detach(), logged={k: (v.detach() if torch.is_tensor(v) else v) for k, v in m._logged.items()},
+        grads={n: params[n].grad.clone() for n in names if params[n].grad is not None},
+    ), OUT / 'f8_training_step.pt')
+
+
+def f9_lora_targets(R):
+    """LoRA target / modules_to_save discovery (mmmm/utils.py:19-61, mmmm.py:157-165) at 1+1 layers"""
+    res = {}
+    for freeze in (True, False):
+        m, cfg = build_tiny_model(R, True, seed=90, n_lm=1, n_vit=1)
+        if freeze:
+            m.sam.requires_grad_(False)
+            m.isam_model.requires_grad_(False)
+        m._freeze_sam_unused()
+        m.model.config.lora_lang = True
+        target, save = m.get_lora_modules(prefix='')
+        res[f'freeze_sam={freeze}'] = dict(target_modules=target, modules_to_save=save)
+    torch.save(res, OUT / 'f9_lora_targets.pt')
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    R = ref_shims.load()
+    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets):
+        fn(R)
+        print('wrote', fn.__name__)
+    for p in sorted(OUT.glob('*.pt')):
+        print(p.name, os.path.getsize(p) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()
