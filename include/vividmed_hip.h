@@ -205,6 +205,16 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 
+/* same, restricted to one row segment of the token-routed layout:
+ * segment 0 = rows [0, counts[0]), segment 1 = rows [counts[0], counts[1]) (device counts);
+ * out[c, i] = in[begin + i, c], zero beyond the segment. Feeds the per-expert LoRA weight gradients. */
+int vm_transpose_segment(const void* in, int64_t ld_in, void* out, int64_t ld_out,
+                         int rows, int cols, int dtype, const int32_t* counts_dev, int segment, void* stream);
+
+/* out_accum[c] += sum_r x[r, c] (fp32, atomically accumulated: zero it first). Bias gradients. */
+int vm_colsum(const void* x, int64_t ld, float* out_accum, int rows, int cols, int dtype,
+              const int32_t* nrows_dev, void* stream);
+
 /* ------------------------------------------------------------------------
  * Per-token weighted cross-entropy over the vocabulary —
  * _sample_weighted_ce, modeling_cogvlm.py:610-627, fed by lm_head :701.

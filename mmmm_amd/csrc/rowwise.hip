@@ -406,10 +406,18 @@ __global__ __launch_bounds__(256) void embedding_bwd_k(
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int64_t ld_in,
                                                    T* __restrict__ out, int64_t ld_out,
-                                                   int rows, int cols, const int32_t* nrows_dev) {
+                                                   int rows, int cols, const int32_t* nrows_dev,
+                                                   const int32_t* range_dev, int segment) {
   __shared__ T tile[64][64 + 2];
   int rows_true = rows;
   if (nrows_dev) rows_true = min(rows, *nrows_dev);
+  if (range_dev) {
+    // rows [begin, end) of the token-routed layout: segment 0 = [0, counts[0]), 1 = [counts[0], counts[1])
+    const int begin = segment ? range_dev[0] : 0;
+    const int end = segment ? range_dev[1] : range_dev[0];
+    in += (int64_t)begin * ld_in;
+    rows_true = min(rows, max(end - begin, 0));
+  }
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   for (int i = ty; i < 64; i += 4) {
@@ -423,6 +431,18 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
     const int c = c0 + i, r = r0 + tx;
     if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
   }
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
+                                                int rows, int cols, const int32_t* nrows_dev) {
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) acc += Elem<T>::ld(x[(int64_t)r * ld + c]);
+  atomicAdd(out + c, acc);
 }
 
 // ---------------------------------------------------------------- cross entropy
@@ -702,7 +722,28 @@ int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int r
   if (rows <= 0 || cols <= 0) return VM_OK;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
-                                           ld_in, (T*)out, ld_out, rows, cols, nrows_dev));
+                                           ld_in, (T*)out, ld_out, rows, cols, nrows_dev, (const int32_t*)nullptr, 0));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_transpose_segment(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
+                         const int32_t* counts_dev, int segment, void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  if (!counts_dev || (segment != 0 && segment != 1)) return VM_ERR_BAD_ARG;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                                           ld_in, (T*)out, ld_out, rows, cols, (const int32_t*)nullptr, counts_dev, segment));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_colsum(const void* x, int64_t ld, float* out_accum, int rows, int cols, int dtype,
+              const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  dim3 grid((cols + 255) / 256, min((rows + 63) / 64, 128));
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld,
+                                           out_accum, rows, cols, nrows_dev));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -93,6 +93,24 @@ def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = 
     return out
 
 
+def transpose_segment(x: torch.Tensor, counts: torch.Tensor, segment: int, pad_to: int = 64) -> torch.Tensor:
+    """transpose of row segment `segment` (0: [0,counts[0]), 1: [counts[0],counts[1])) -> [cols, rows_padded]"""
+    rows, cols = x.shape
+    rp = (rows + pad_to - 1) // pad_to * pad_to
+    out = torch.empty(cols, rp, dtype=x.dtype, device=x.device)
+    if rp > rows:
+        out[:, rows:].zero_()
+    hip.call('vm_transpose_segment', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(counts), segment, stream())
+    return out
+
+
+def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    hip.call('vm_colsum', ptr(x), _ld(x), ptr(out), x.shape[0], x.shape[1], dtype_code(x.dtype), ptr(nrows), stream())
+    return out
+
+
 # ------------------------------------------------------------------ norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tensor | None = None):
     x = _c(x)

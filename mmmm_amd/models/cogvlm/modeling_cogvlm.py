@@ -1,0 +1,331 @@
+"""CogVLM language model (Vicuna-7B + visual expert) on the MI355X HIP kernels.
+
+Same module / parameter names and the same forward surface as the reference
+(/root/reference/mmmm/models/cogvlm/modeling_cogvlm.py), different execution model:
+
+* activations live in ONE packed, expert-sorted row layout `[T, hidden]` (no padding rows):
+  rows [0, n_vision) are the tokens get_expert_mask routes to the vision expert, rows [n_vision, T) the
+  language-expert tokens; the maps are built on the device by vm_expert_index_build (no host sync).
+  Every token-type gated linear (reference :87-98, :243-245, :277-279) is then ONE 2-segment grouped
+  MFMA GEMM with the LoRA update accumulated in the same fp32 tile, instead of 2 boolean gathers,
+  2 GEMMs (+2 LoRA GEMM pairs) and 2 scatters into a zero tensor.
+* attention is the var-len causal flash kernel, reading sequence positions through `row_of_pos`.
+* lm_head + `.float()` + weighted CE (reference :701-706, :610-627) is one fused operator that never
+  materialises fp32 logits.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from ... import functional as Fh
+from ... import kernels as K
+from ..lora import Linear, gated_linear
+from .configuration_cogvlm import CogVLMConfig
+from .visual import EVA2CLIPModel
+
+LANGUAGE_TOKEN_TYPE, VISION_TOKEN_TYPE = 0, 1
+CE_IGNORE_INDEX = -100
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
+        return Fh.rms_norm(x, self.weight, self.variance_epsilon, nrows)
+
+
+class MLP(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.gate_proj = Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+
+class VisionExpertMLP(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.config = config
+        self.language_mlp = MLP(config)
+        self.vision_mlp = MLP(config)
+
+    def get_lora_modules(self, prefix: str):
+        from ...utils import apply_prefix, get_lora_modules_default
+        if self.config.lora_lang:
+            return get_lora_modules_default(self, prefix, False)
+        return get_lora_modules_default(self.vision_mlp, apply_prefix(prefix, 'vision_mlp'))
+
+    def forward(self, x: torch.Tensor, counts: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        v, l = self.vision_mlp, self.language_mlp
+        gate = gated_linear(x, v.gate_proj, l.gate_proj, counts)
+        up = gated_linear(x, v.up_proj, l.up_proj, counts)
+        return gated_linear(Fh.silu_mul(gate, up), v.down_proj, l.down_proj, counts, residual=residual)
+
+
+class RotaryEmbedding(nn.Module):
+    """cos/sin tables exactly as the reference builds them (:156-170): in the dtype of `inv_freq`, which
+    follows the module dtype (bf16 under bf16-true), `t = arange(dtype=inv_freq.dtype)` included — the
+    bf16 position quirk of SURVEY.md §7 is reproduced by construction. The kernel reads fp32 copies."""
+
+    def __init__(self, dim: int, base: float = 10000.0):
+        super().__init__()
+        self.dim, self.base = dim, base
+        self.register_buffer('inv_freq', 1.0 / (base ** (torch.arange(0, dim, 2) / dim)), persistent=False)
+        self._cache: tuple | None = None
+
+    def tables(self, n_pos: int, device) -> tuple[torch.Tensor, torch.Tensor]:
+        key = (n_pos, self.inv_freq.dtype, str(device))
+        if self._cache is None or self._cache[0] != key:
+            inv = self.inv_freq.to(device)
+            t = torch.arange(n_pos, device=device, dtype=inv.dtype)
+            freqs = torch.einsum('i,j->ij', t, inv)
+            emb = torch.cat((freqs, freqs), dim=-1)
+            self._cache = (key, emb.cos().float().contiguous(), emb.sin().float().contiguous())
+        return self._cache[1], self._cache[2]
+
+
+@dataclass
+class Routing:
+    """device-side token routing of one batch (built once per forward, shared by all layers)"""
+    counts: torch.Tensor        # int32[4]: n_vision_rows, n_rows, max_seqlen, 0
+    row_of_tok: torch.Tensor    # int32[B*L]
+    tok_of_row: torch.Tensor    # int32[B*L]
+    cu_seqlens: torch.Tensor    # int32[B+1]
+    row_of_pos: torch.Tensor    # int32[B*L]
+    expert_mask: torch.Tensor   # uint8[B,L]
+    row_pos: torch.Tensor       # int32[B*L] position id of each row
+    n_rows: torch.Tensor        # int32[1] view of counts[1]
+    B: int
+    L: int
+    n_pos: int                  # rope table length (upper bound, host)
+
+
+class VisionExpertAttention(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.rotary_emb = RotaryEmbedding(self.head_dim)
+        self.vision_expert_query_key_value = Linear(self.hidden_size, self.hidden_size * 3, bias=False)
+        self.vision_expert_dense = Linear(self.hidden_size, self.hidden_size, bias=False)
+        self.language_expert_query_key_value = Linear(self.hidden_size, self.hidden_size * 3, bias=False)
+        self.language_expert_dense = Linear(self.hidden_size, self.hidden_size, bias=False)
+
+    def get_lora_modules(self, prefix: str):
+        from ...utils import apply_prefix, get_lora_modules_default
+        if self.config.lora_lang:
+            return get_lora_modules_default(self, prefix, False)
+        return [apply_prefix(prefix, 'vision_expert_query_key_value'), apply_prefix(prefix, 'vision_expert_dense')], []
+
+    def forward(self, x: torch.Tensor, rt: Routing, residual: torch.Tensor) -> torch.Tensor:
+        qkv = gated_linear(x, self.vision_expert_query_key_value, self.language_expert_query_key_value, rt.counts)
+        cos, sin = self.rotary_emb.tables(rt.n_pos, x.device)
+        qkv = Fh.rope_(qkv, rt.row_pos, cos, sin, self.num_heads, self.head_dim, rt.n_rows)
+        ctx = Fh.attention(qkv, rt.cu_seqlens, rt.L, self.num_heads, self.head_dim, self.head_dim ** -0.5, True,
+                           row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L)
+        return gated_linear(ctx, self.vision_expert_dense, self.language_expert_dense, rt.counts, residual=residual)
+
+
+class CogVLMDecoderLayer(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.self_attn = VisionExpertAttention(config)
+        self.mlp = VisionExpertMLP(config)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, x: torch.Tensor, rt: Routing) -> torch.Tensor:
+        x = self.self_attn(self.input_layernorm(x, rt.n_rows), rt, residual=x)
+        return self.mlp(self.post_attention_layernorm(x, rt.n_rows), rt.counts, residual=x)
+
+
+class PackedHidden:
+    """hidden states in the packed layout, exposed in the reference's padded `[B, L, h]` form on demand"""
+
+    def __init__(self, packed: list[torch.Tensor], rt: Routing):
+        self._packed, self._rt = packed, rt
+
+    def __len__(self):
+        return len(self._packed)
+
+    def packed(self, i: int) -> torch.Tensor:
+        return self._packed[i]
+
+    def __getitem__(self, i: int) -> torch.Tensor:
+        rt = self._rt
+        x = self._packed[i]
+        out = Fh.gather_rows(x, rt.row_of_tok, rt.B * rt.L)     # padded rows -> zeros (undefined in the reference)
+        return out.view(rt.B, rt.L, x.shape[-1])
+
+
+class CogVLMModel(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.config = config
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.layers = nn.ModuleList([CogVLMDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.vision = EVA2CLIPModel(config)
+        self.gradient_checkpointing = False
+
+    def get_lora_modules(self, prefix: str):
+        """the whole embedding layer is fine-tuned; everything else by the default rule (reference :412-421)"""
+        from ...utils import apply_prefix, get_lora_modules_default
+        targets, saves = [], [apply_prefix(prefix, 'embed_tokens')]
+        for name, child in self.named_children():
+            if name == 'embed_tokens':
+                continue
+            t, s = get_lora_modules_default(child, apply_prefix(prefix, name))
+            targets.extend(t)
+            saves.extend(s)
+        return targets, saves
+
+    def build_routing(self, token_type_ids, attention_mask, position_ids) -> Routing:
+        B, L = token_type_ids.shape
+        r = K.expert_index_build(token_type_ids, attention_mask)
+        pos = position_ids.reshape(-1).to(torch.int32)
+        row_pos = pos[r['tok_of_row'].clamp_min(0).long()].contiguous()
+        n_pos = int(self.config.max_position_embeddings)
+        return Routing(counts=r['counts'], row_of_tok=r['row_of_tok'], tok_of_row=r['tok_of_row'], cu_seqlens=r['cu_seqlens'],
+                       row_of_pos=r['row_of_pos'], expert_mask=r['expert_mask'], row_pos=row_pos, n_rows=r['counts'][1:2],
+                       B=B, L=L, n_pos=n_pos)
+
+    def forward(self, input_ids, *, image=None, patch_size=None, pool_size=None, token_type_ids=None, attention_mask=None,
+                position_ids=None, output_hidden_states: bool = False):
+        B, L = input_ids.shape
+        dev = input_ids.device
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        if position_ids is None:
+            position_ids = torch.arange(L, device=dev)[None].expand(B, L)
+        rt = self.build_routing(token_type_ids, attention_mask, position_ids)
+        # token ids per packed row; rows that will be overwritten by image features look up nothing (-1)
+        ids = input_ids.reshape(-1).to(torch.int32)
+        feats = None
+        if image is not None:
+            assert len(image) == B, f'batch size mismatch: {B} {len(image)}'
+            feats = self.vision(image, patch_size, pool_size)
+            tok = torch.arange(B * L, device=dev).view(B, L)
+            img_tok = torch.cat([tok[i, 1:1 + f.shape[0]] for i, f in enumerate(feats)])
+            ids = ids.clone()
+            ids[img_tok] = -1
+        row_ids = torch.where(rt.tok_of_row >= 0, ids[rt.tok_of_row.clamp_min(0).long()], torch.full_like(ids, -1))
+        x = Fh.embedding_rows(self.embed_tokens.weight, row_ids.contiguous())
+        if feats is not None:
+            x = Fh.overwrite_rows_(x, torch.cat(feats, dim=0).to(x.dtype), rt.row_of_tok[img_tok].contiguous())
+        hs = [] if output_hidden_states else None
+        for layer in self.layers:
+            if hs is not None:
+                hs.append(x)
+            if self.gradient_checkpointing and self.training:
+                x = checkpoint(layer, x, rt, use_reentrant=False, preserve_rng_state=False)
+            else:
+                x = layer(x, rt)
+        x = self.norm(x, rt.n_rows)
+        if hs is not None:
+            hs.append(x)
+        return x, rt, (PackedHidden(hs, rt) if hs is not None else None)
+
+
+class _LMHeadCE(torch.autograd.Function):
+    """lm_head GEMM -> bf16 logits -> fp32 weighted CE, without an fp32 [T, vocab] round trip
+    (reference :701 `self.lm_head(h).float()` then _sample_weighted_ce :610-627)."""
+
+    @staticmethod
+    def forward(ctx, h, W, labels, weight, nrows):
+        V, Kd = W.shape
+        Vp = (V + 63) // 64 * 64
+        logits = torch.empty(h.shape[0], Vp, dtype=h.dtype, device=h.device)
+        if Vp > V:
+            logits[:, V:].zero_()
+        K.gemm(h, W, out=logits[:, :V])
+        row_ce, lse = K.ce_fwd(logits, labels, V, nrows)
+        valid = labels >= 0
+        n_valid = valid.sum().clamp_min(1).to(torch.float32)
+        w = torch.where(valid, weight.to(torch.float32), torch.zeros((), device=h.device))
+        loss = torch.dot(row_ce, w) / n_valid
+        ctx.save_for_backward(h, W, labels, lse, w / n_valid, nrows, logits)
+        ctx.mark_non_differentiable(row_ce)
+        return loss, row_ce
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dloss, _):
+        h, W, labels, lse, scale, nrows, logits = ctx.saved_tensors
+        V = W.shape[0]
+        d = K.ce_bwd(logits, labels, lse, scale * dloss.to(torch.float32), V, nrows, out=logits)   # in place, pad cols = 0
+        dh = dW = None
+        if ctx.needs_input_grad[0]:
+            dh = K.gemm(d, K.transpose(W.detach(), pad_to=64))              # K = padded vocab
+        if ctx.needs_input_grad[1]:
+            dW = K.gemm(K.transpose(d[:, :V], pad_to=64), K.transpose(h, pad_to=64, nrows=nrows))
+        return dh, dW, None, None, None
+
+
+@dataclass
+class CausalLMOutputWithPast:
+    """the fields of transformers' CausalLMOutputWithPast that the reference's callers read"""
+    loss: torch.Tensor | None = None
+    logits: torch.Tensor | None = None
+    past_key_values: object = None
+    hidden_states: PackedHidden | None = None
+    attentions: object = None
+    # extras of this implementation (packed layout)
+    row_ce: torch.Tensor | None = None
+    row_labels: torch.Tensor | None = None
+    routing: Routing | None = None
+    last_hidden_packed: torch.Tensor | None = None
+
+
+class CogVLMForCausalLM(nn.Module):
+    def __init__(self, config: CogVLMConfig):
+        super().__init__()
+        self.config = config
+        self.model = CogVLMModel(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    def gradient_checkpointing_enable(self, kwargs: dict | None = None):
+        self.model.gradient_checkpointing = True
+        self.model.vision.transformer.gradient_checkpointing = True
+
+    def forward(self, input_ids=None, *, image=None, patch_size=None, pool_size=None, token_type_ids=None,
+                attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, weight=None,
+                materialize_logits: bool = False) -> CausalLMOutputWithPast:
+        if past_key_values is not None or inputs_embeds is not None:
+            raise NotImplementedError('generation path (SURVEY.md §8f N4) is out of scope of the training step')
+        x, rt, hs = self.model(input_ids, image=image, patch_size=patch_size, pool_size=pool_size, token_type_ids=token_type_ids,
+                               attention_mask=attention_mask, position_ids=position_ids,
+                               output_hidden_states=bool(output_hidden_states))
+        out = CausalLMOutputWithPast(hidden_states=hs, routing=rt, last_hidden_packed=x)
+        if labels is not None:
+            tok = rt.tok_of_row.clamp_min(0).long()
+            row_labels = torch.where(rt.tok_of_row >= 0, labels.reshape(-1)[tok], torch.full_like(tok, CE_IGNORE_INDEX)).contiguous()
+            if weight is None:
+                row_w = torch.ones(row_labels.shape, device=x.device)
+            else:
+                row_w = weight.reshape(-1)[tok].float()
+            loss, row_ce = _LMHeadCE.apply(x, self.lm_head.weight, row_labels, row_w, rt.n_rows)
+            if weight is None:
+                pass  # F.cross_entropy mean over valid labels == weighted form with unit weights
+            out.loss, out.row_ce = loss, row_ce
+            out.row_labels = row_labels
+        if materialize_logits or labels is None:
+            lg = K.gemm(x.detach(), self.lm_head.weight.detach())
+            full = K.gather_rows(lg, rt.row_of_tok, rt.B * rt.L)
+            out.logits = full.view(rt.B, rt.L, -1).float()
+        return out

@@ -1,0 +1,153 @@
+"""EVA2-CLIP-E image encoder of CogVLM on the MI355X HIP kernels.
+
+Module / parameter names follow /root/reference/mmmm/models/cogvlm/visual.py. All images of a batch are
+packed into one `[sum Nv, 1792]` sequence (var-len, per-image blocks) like the reference does with
+xformers' BlockDiagonalMask; attention is the non-causal var-len flash kernel at head_dim 112.
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+from ... import functional as Fh
+from ..lora import Linear
+from ..resample import Downsample, resample
+
+
+class ParameterWrapper(nn.Module):
+    """mmmm/utils.py:62-77 — a bare parameter exposed as `<name>.weight` so PEFT's modules_to_save can hold it"""
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(weight)
+
+
+class PatchEmbedding(nn.Module):
+    def __init__(self, config: Namespace):
+        super().__init__()
+        self.proj = Downsample(config.in_channels, config.hidden_size, config.patch_size)
+        self.pos_embed_shape = tuple(config.pos_embed_shape)
+        self.cls_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size))
+        self.cls_pos_embed = ParameterWrapper(torch.zeros(1, config.hidden_size))
+        self.position_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size, *config.pos_embed_shape))
+
+    def forward(self, image_list: list[torch.Tensor], patch_size_list: list[tuple]):
+        """-> packed tokens [sum Nv, C], cu_seqlens (host list), grid shapes (visual.py:59-77)"""
+        xs, shapes = [], []
+        cls = self.cls_embedding.weight + self.cls_pos_embed.weight
+        for image, patch in zip(image_list, patch_size_list):
+            x, shape = self.proj(image, patch)
+            pos = resample(self.position_embedding.weight, shape)            # [1, C, d, h, w]
+            x = x + pos[0].flatten(1).t().to(x.dtype)
+            xs.append(torch.cat([cls.to(x.dtype), x], dim=0))
+            shapes.append(shape)
+        lens = [t.shape[0] for t in xs]
+        return torch.cat(xs, dim=0), lens, shapes
+
+
+class Attention(nn.Module):
+    def __init__(self, config: Namespace):
+        super().__init__()
+        self.num_heads = config.num_heads
+        self.head_dim = config.hidden_size // config.num_heads
+        self.scale = self.head_dim ** -0.5
+        self.query_key_value = Linear(config.hidden_size, config.hidden_size * 3)
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+
+    def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
+        qkv = self.query_key_value(x)
+        out = Fh.attention(qkv, cu, max_len, self.num_heads, self.head_dim, self.scale, False)
+        return self.dense(out)
+
+
+class MLP(nn.Module):
+    def __init__(self, config: Namespace):
+        super().__init__()
+        self.fc1 = Linear(config.hidden_size, config.intermediate_size)
+        self.fc2 = Linear(config.intermediate_size, config.hidden_size)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.fc2(Fh.gelu(self.fc1(x)))
+
+
+class TransformerLayer(nn.Module):
+    """LayerNorm on the branch OUTPUT: x + LN(attn(x)), x + LN(mlp(x)) (visual.py:134-141)"""
+    def __init__(self, config: Namespace):
+        super().__init__()
+        self.input_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.attention = Attention(config)
+        self.mlp = MLP(config)
+        self.post_attention_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
+        ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
+        x = Fh.layer_norm(self.attention(x, cu, max_len), ln1.weight, ln1.bias, ln1.eps, residual=x)
+        return Fh.layer_norm(self.mlp(x), ln2.weight, ln2.bias, ln2.eps, residual=x)
+
+
+class Transformer(nn.Module):
+    def __init__(self, config: Namespace):
+        super().__init__()
+        self.gradient_checkpointing = False
+        self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
+        for layer in self.layers:
+            if self.gradient_checkpointing and self.training:
+                x = checkpoint(layer, x, cu, max_len, use_reentrant=False, preserve_rng_state=False)
+            else:
+                x = layer(x, cu, max_len)
+        return x
+
+
+class GLU(nn.Module):
+    def __init__(self, config, in_features: int):
+        super().__init__()
+        self.linear_proj = Linear(in_features, config.hidden_size, bias=False)
+        self.norm1 = nn.LayerNorm(config.hidden_size)
+        self.dense_h_to_4h = Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.gate_proj = Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.dense_4h_to_h = Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.linear_proj(x)
+        x = Fh.gelu(Fh.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        x = Fh.silu_mul(self.gate_proj(x), self.dense_h_to_4h(x))
+        return self.dense_4h_to_h(x)
+
+
+class EVA2CLIPModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        vc = Namespace(**config.vision_config)
+        self.patch_embedding = PatchEmbedding(vc)
+        self.transformer = Transformer(vc)
+        self.linear_proj = GLU(config, in_features=vc.hidden_size)
+        self.boi = nn.Parameter(torch.zeros(1, 1, config.hidden_size))
+        self.eoi = nn.Parameter(torch.zeros(1, 1, config.hidden_size))
+
+    def forward(self, image: list[torch.Tensor], patch_size: list[tuple], pool_size_list: list[tuple]) -> list[torch.Tensor]:
+        """-> per image [Np + 2, hidden] (boi, pooled patches through the GLU adapter, eoi) — visual.py:192-208"""
+        x, lens, shapes = self.patch_embedding(image, patch_size)
+        cu_host = [0]
+        for n in lens:
+            cu_host.append(cu_host[-1] + n)
+        cu = torch.tensor(cu_host, dtype=torch.int32, device=x.device)
+        x = self.transformer(x, cu, max(lens))
+        pooled, counts = [], []
+        for i, (shape, pool) in enumerate(zip(shapes, pool_size_list)):
+            t = x[cu_host[i] + 1:cu_host[i + 1]]
+            if any(p > 1 for p in pool):
+                t = t.t().reshape(1, -1, *shape)
+                t = F.max_pool3d(t, tuple(pool))
+                t = t.flatten(2)[0].t()
+            pooled.append(t)
+            counts.append(t.shape[0])
+        y = self.linear_proj(torch.cat(pooled, dim=0).contiguous())       # one GEMM chain for the whole batch
+        outs = []
+        for t in y.split(counts):
+            outs.append(torch.cat([self.boi[0].to(t.dtype), t, self.eoi[0].to(t.dtype)], dim=0))
+        return outs

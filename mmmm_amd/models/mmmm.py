@@ -1,0 +1,280 @@
+"""MMMMForCausalLM — the VividMed training step on MI355X behind the reference's LightningModule surface.
+
+Mirrors /root/reference/mmmm/models/mmmm.py: `build(...)` keyword arguments, `training_step(batch)`,
+`forward(...)`, `visual_grounding(...)`, `get_lora_modules`, `get_fp32_children`, `on_fit_start`,
+`on_load_checkpoint`, `MyPrecision`. Lightning itself is not in the image; the class is a plain nn.Module with
+the hooks the Trainer calls (log / log_dict record into `self.logged`), so a Lightning shell can subclass it
+unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+from torch import nn
+
+from .. import functional as Fh
+from ..utils import apply_prefix, get_lora_modules_default, get_lora_modules_finetune_all
+from .cogvlm.configuration_cogvlm import CogVLMConfig
+from .cogvlm.modeling_cogvlm import CausalLMOutputWithPast, CogVLMForCausalLM
+from .lora import Linear, StepState
+from .loss import DiceFocalLoss
+
+__all__ = ['MMMMForCausalLM', 'build', 'VisionArgs', 'MyPrecision']
+
+
+@dataclass
+class VisionArgs:
+    pos_embed_shape: tuple
+    pt_pos_embed_shape: tuple | None = None
+    patch_size: Any = 16
+
+
+@dataclass
+class VisualGroundingOutput:
+    masks_logits: list = field(default_factory=list)
+    masks_logits_ds: list = field(default_factory=list)
+    boxes: list = field(default_factory=list)
+    disc_logit: list = field(default_factory=list)
+
+
+def zero_loss(*tensors) -> torch.Tensor:
+    """luolib.losses.zero_loss: a graph-connected 0 so every parameter receives a (zero) gradient"""
+    out = None
+    for t in tensors:
+        if t is None:
+            continue
+        z = 0 * t.sum()
+        out = z if out is None else out + z
+    return out if out is not None else torch.zeros((), device='cuda')
+
+
+def _add_prefix(d: dict, prefix: str) -> dict:
+    if prefix and not prefix.endswith('/'):
+        prefix += '/'
+    return {f'{prefix}{k}': v for k, v in d.items()}
+
+
+class _Trainer:
+    is_parallel = False
+
+
+class MMMMForCausalLM(CogVLMForCausalLM):
+    def __init__(self, vlm_config: CogVLMConfig, *, vision_override: VisionArgs | None = None):
+        if vision_override is not None:
+            vc = vlm_config.vision_config
+            vc['pos_embed_shape'] = tuple(vision_override.pos_embed_shape)
+            if vision_override.pt_pos_embed_shape is not None:
+                vc['pt_pos_embed_shape'] = tuple(vision_override.pt_pos_embed_shape)
+            p = vision_override.patch_size
+            vc['patch_size'] = (p, p, p) if isinstance(p, int) else tuple(p)
+        super().__init__(vlm_config)
+        self.tokenizer = None
+        self.lm_loss_weight = 1.0
+        self.sam = None
+        self.mask_loss = None
+        self.isam_model = None
+        self.isam_loss = None
+        self.trainer = _Trainer()
+        self.logged: dict[str, torch.Tensor] = {}
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def build(cls, pretrained_model_name_or_path=None, *args, vision_override: VisionArgs, tokenizer=None,
+              torch_dtype='auto', freeze_vision: bool = False, lm_loss_weight: float = 1., sam=None, freeze_sam: bool = True,
+              mask_loss: DiceFocalLoss | None = None, isam=None, freeze_isam: bool = True, isam_loss=None,
+              config: CogVLMConfig | None = None):
+        """Same keyword surface as the reference's `build` (mmmm.py:82-135). Base weights are loaded from
+        `pretrained_model_name_or_path` when it is a local checkpoint directory (checkpoint loaders: SURVEY §8f N3);
+        with None the model is randomly initialised (benchmarks / tests: no weights or network in the image)."""
+        self = cls(config or CogVLMConfig(), vision_override=vision_override)
+        if pretrained_model_name_or_path is not None:
+            from .checkpoint import load_pretrained
+            load_pretrained(self, pretrained_model_name_or_path)
+        self.tokenizer = tokenizer
+        self.lm_loss_weight = lm_loss_weight
+        self.sam, self.mask_loss, self.isam_model, self.isam_loss = sam, mask_loss, isam, isam_loss
+        if sam is not None:
+            assert isam is not None
+            if freeze_sam:
+                sam.requires_grad_(False)
+                sam.eval()
+            if freeze_isam:
+                isam.requires_grad_(False)
+                isam.eval()
+            self._freeze_sam_unused()
+            assert sam.prompt_dim == isam.prompt_dim
+            h = self.config.hidden_size
+            self.vg_proj = nn.Sequential(Linear(h, h), nn.ReLU(inplace=True), Linear(h, sam.prompt_dim))
+            if isam_loss is not None:
+                isam_loss.mask_loss = mask_loss
+        if freeze_vision:
+            self.model.vision.requires_grad_(False)
+        self.model.config.lora_lang = not freeze_vision
+        return self
+
+    def _freeze_sam_unused(self):
+        sam, isam = self.sam, self.isam_model
+        for m in (sam.prompt_encoder.point_embeddings, sam.prompt_encoder.not_a_point_embed, sam.prompt_encoder.mask_downscaling,
+                  isam.prompt_encoder.point_embeddings, isam.prompt_encoder.not_a_point_embed, isam.prompt_encoder.mask_downscaling,
+                  isam.mask_decoder.output_upscaling, isam.mask_decoder.output_hypernetworks_mlps,
+                  isam.mask_decoder.txt_align_upscaled_embedding):
+            m.requires_grad_(False)
+
+    def get_fp32_children(self) -> list[str]:
+        return ['sam', 'isam_model', 'vg_proj']
+
+    def on_load_checkpoint(self, checkpoint: dict):
+        checkpoint['state_dict'] = {}
+        self.strict_loading = False
+
+    def on_fit_start(self) -> None:
+        self.gradient_checkpointing_enable({'use_reentrant': False})
+
+    def get_lora_modules(self, prefix: str):
+        targets, saves = get_lora_modules_default(self.model, apply_prefix(prefix, 'model'))
+        for name, child in self.named_children():
+            if name == 'model':
+                continue
+            saves.extend(get_lora_modules_finetune_all(child, apply_prefix(prefix, name)))
+        return targets, saves
+
+    # -- logging hooks (Lightning's names) -------------------------------------------------------
+    def log(self, name: str, value, **kwargs):
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    def log_dict(self, d: dict, **kwargs):
+        for k, v in d.items():
+            self.log(k, v)
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    # -- grounding -------------------------------------------------------------------------------
+    def _get_vg_prompts(self, token_ids, hidden_states, prompt_mask):
+        """mmmm.py:167-178: hidden states at </p> -> vg_proj (fp32)"""
+        eop_mask = token_ids == self.tokenizer.eop_token_id
+        x = hidden_states[eop_mask]
+        x = self.vg_proj[2](Fh.relu(self.vg_proj[0](x)))
+        prompts = x.split(eop_mask.sum(dim=-1).tolist())
+        return [p if m is None else p[m] for p, m in zip(prompts, prompt_mask)]
+
+    def visual_grounding(self, token_ids, hidden_states, image, patch_size, prompt_mask, instance_mask):
+        """mmmm.py:180-223"""
+        if instance_mask is None:
+            raise NotImplementedError
+        B = len(image)
+        vg_prompts = self._get_vg_prompts(token_ids, hidden_states, prompt_mask)
+        masks_logits: list = [None] * B
+        boxes: list = [None] * B
+        disc_logit: list = [None] * B
+        sem = [i for i in range(B) if not instance_mask[i]]
+        ins = [i for i in range(B) if instance_mask[i]]
+        if sem:
+            out = self.sam([image[i] for i in sem], [patch_size[i] for i in sem], [vg_prompts[i] for i in sem])
+            for i, m in zip(sem, out):
+                masks_logits[i] = m
+        if ins:
+            out = self.isam_model([image[i] for i in ins], [patch_size[i] for i in ins], [vg_prompts[i] for i in ins])
+            for i, b, d in zip(ins, out.boxes, out.disc_logit):
+                boxes[i], disc_logit[i] = b, d
+        return masks_logits, boxes, disc_logit
+
+    def _compute_vg_loss(self, masks_logits, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets):
+        """mmmm.py:225-285"""
+        B = len(masks_logits)
+        loss_list, log_dict = [], {}
+        for i in range(B):
+            if boxes_label[i] is not None:
+                if masks_label[i] is not None:
+                    raise NotImplementedError('instance segmentation is not supported yet')
+                dummy = boxes_reg[i].new_empty((*boxes_reg[i].shape[:2], 0, 0, 0))
+                loss_, log_ = self.isam_loss.compute_loss(dummy, dummy, boxes_reg[i], disc_logit[i], None, boxes_label[i], index_offsets[i])
+                loss_ = loss_ + zero_loss(masks_logits[i])
+            elif masks_label[i] is not None and masks_label[i].shape[0] > 0:
+                log_ = self.mask_loss(masks_logits[i][:, None], masks_label[i][:, None], return_dict=True)
+                loss_ = log_.pop('total') + zero_loss(disc_logit[i], boxes_reg[i])
+            else:
+                loss_ = zero_loss(masks_logits[i], disc_logit[i], boxes_reg[i])
+                log_ = {}
+            loss_list.append(loss_)
+            for k, v in log_.items():
+                log_dict.setdefault(k, []).append(v)
+        loss = torch.stack(loss_list).mean()
+        if self.trainer.is_parallel:
+            # every rank must touch every trainable head so the gradient all-reduce sees identical buckets
+            # (reference mmmm.py:263-278); the bucketed all-reduce of mmmm_amd.ddp zero-fills instead, so
+            # the dummy forward is only needed when SAM parameters are trainable AND unused on this rank.
+            dev = self.device
+            if all(m is None for m in masks_logits) and any(p.requires_grad for p in self.sam.parameters()):
+                loss = loss + zero_loss(self.sam([torch.zeros(3, 2, 32, 32, device=dev)], [(1, 16, 16)],
+                                                 [torch.zeros(1, self.sam.prompt_dim, device=dev)])[0])
+            if all(b is None for b in boxes_reg) and any(p.requires_grad for p in self.isam_model.parameters()):
+                out = self.isam_model([torch.zeros(3, 2, 32, 32, device=dev)], [(1, 16, 16)],
+                                      [torch.zeros(1, self.sam.prompt_dim, device=dev)])
+                loss = loss + zero_loss(out.disc_logit[0], out.boxes[0])
+        with torch.no_grad():
+            log_dict = {k: torch.stack(v).mean() for k, v in log_dict.items()}
+        return loss, log_dict
+
+    # -- the step ----------------------------------------------------------------------------------
+    def training_step(self, batch: dict, *args, **kwargs):
+        """mmmm.py:296-352"""
+        StepState.step += 1
+        vlm_inputs = batch['vlm_inputs']
+        input_ids = vlm_inputs['input_ids']
+        out: CausalLMOutputWithPast = self(**vlm_inputs, image=batch['image'], patch_size=batch['patch_size'],
+                                           pool_size=batch['pool_size'], return_dict=True, output_hidden_states=True)
+        if self.sam is None:
+            self.log('train/loss', out.loss, sync_dist=True)
+            return self.lm_loss_weight * out.loss
+        B = input_ids.shape[0]
+        masks_logits, boxes, disc_logit = self.visual_grounding(
+            input_ids[:, 1:], out.hidden_states[-1][:, :-1].float(), batch['grounding_image'], batch['patch_size'],
+            batch.get('vg_label_mask') or [None] * B, batch['instance_mask'],
+        )
+        vg_loss, vg_log = self._compute_vg_loss(masks_logits, boxes, disc_logit, batch['masks'], batch['boxes'], batch['index_offsets'])
+        loss = out.loss * self.lm_loss_weight + vg_loss
+        logs = {'train/loss': loss, 'train/lm_loss': out.loss, 'train/vg_loss': vg_loss, **_add_prefix(vg_log, 'train/vg')}
+        # per-token CE on the <p> / </p> targets: the unweighted row CE is already a by-product of the fused lm_head+CE
+        with torch.no_grad():
+            for name, tid in (('bop', self.tokenizer.bop_token_id), ('eop', self.tokenizer.eop_token_id)):
+                m = out.row_labels == tid
+                n = m.sum()
+                logs[f'train/token-lm/{name}_loss'] = (out.row_ce * m).sum() / n.clamp_min(1)
+                logs[f'train/token-lm/{name}_count'] = n
+        self.log_dict(logs)
+        return loss
+
+
+def build(*args, **kwargs) -> MMMMForCausalLM:
+    return MMMMForCausalLM.build(*args, **kwargs)
+
+
+class MyPrecision:
+    """the reference's precision plugin (mmmm.py:468-492): everything bf16 except the fp32 islands
+    `sam`, `isam_model`, `vg_proj` and the inputs `grounding_image`, `boxes`."""
+    fp32_input_keys = ('grounding_image', 'boxes')
+
+    def convert_input(self, data: dict) -> dict:
+        def cv(x):
+            if torch.is_tensor(x):
+                return x.to(torch.bfloat16) if x.is_floating_point() else x
+            if isinstance(x, dict):
+                return {k: cv(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return type(x)(cv(v) for v in x)
+            return x
+        out = {k: cv(v) for k, v in data.items() if k not in self.fp32_input_keys}
+        out.update({k: data[k] for k in self.fp32_input_keys if data.get(k) is not None})
+        return out
+
+    def convert_module(self, module: MMMMForCausalLM) -> MMMMForCausalLM:
+        assert isinstance(module, MMMMForCausalLM)
+        fp32 = set(module.get_fp32_children())
+        for name, child in module.named_children():
+            if name not in fp32:
+                child.to(torch.bfloat16)
+        return module
