@@ -17,9 +17,13 @@ def randomize_(module: torch.nn.Module, seed: int):
                 v = 0.05 * torch.randn(p.shape, generator=g)
             else:
                 fan_in = math.prod(p.shape[1:]) if p.ndim >= 2 else p.shape[0]
-                std = 0.5 if (p.ndim < 2 or 'embed' in name or name.endswith(('boi', 'eoi'))) else 1.0 / math.sqrt(fan_in)
+                std = 0.3 if (p.ndim < 2 or 'embed' in name or name.endswith(('boi', 'eoi'))) else 1.0 / math.sqrt(fan_in)
                 if 'lora_B' in name:
                     std = 0.05
+                # keep softmax out of saturation: with saturated attention dq/dk are pure cancellation noise
+                # (P one-hot => dS = P*(dP - delta) ~ 0) and a bf16-vs-fp32 comparison of them is meaningless
+                if 'query_key_value' in name or name.endswith(('qkv.weight', 'q_proj.weight', 'k_proj.weight')):
+                    std *= 0.35
                 v = std * torch.randn(p.shape, generator=g)
             p.copy_(v.to(p.dtype))
         for name, b in module.named_buffers():
