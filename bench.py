@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Benchmark of the VividMed training step on MI355X (BASELINE.json metric: train images/sec/node).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: plain python; N>1: torch.distributed.run)
+
+A "step" = one MMMMForCausalLM.training_step (forward + backward through the HIP kernels, gradient checkpointing as
+the reference's on_fit_start enables it) + bucketed RCCL gradient all-reduce + grad-norm clip (1.0) + AdamW
+(lr 5e-5, wd 0.01 — conf/phase-vg/fit.yaml) on one synthetic batch that is resident in HBM before the timed region.
+Default workload = BASELINE.json configs[1]: phase-vg LoRA bf16, 2D 448x448, batch 8 per GPU, CogVLM-7B + EVA-ViT-E
++ SAM-B + iSAM at full depth, random-init weights (no checkpoints / network in the image), synthetic data.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = bf16 MFMA GEMM,
+timed live with HIP events around every launch on its own stream) and `cpu_baseline` (the CPU oracle on the host
+cores, bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (image shape, patch, pool, text tokens, grounding heads)
+    'phase-vg-448': dict(image=(3, 1, 448, 448), patch=(1, 16, 16), pool=(1, 2, 2), text=256, sam=True,
+                         desc='BASELINE configs[1]: phase-vg LoRA bf16, 2D 448x448, batch 8/GPU, CogVLM-7B + SAM-B + iSAM'),
+    'phase-vlm-448': dict(image=(3, 1, 448, 448), patch=(1, 16, 16), pool=(1, 2, 2), text=256, sam=False,
+                          desc='phase-vlm (sam=None) LoRA bf16, 2D 448x448, batch 8/GPU, CogVLM-7B'),
+    'phase-grg-3d': dict(image=(3, 32, 256, 256), patch=(4, 16, 16), pool=(2, 2, 2), text=256, sam=True,
+                         desc='BASELINE configs[3]: phase-grg 3D CT 32x256x256'),
+}
+
+
+def train_flops_per_sample(w: dict, cfg, sam: bool) -> float:
+    """algorithmic training FLOPs per sample, recompute excluded (SURVEY.md §8d formulas)"""
+    vc = cfg.vision_config
+    d, f, h, i = vc['hidden_size'], vc['intermediate_size'], cfg.hidden_size, cfg.intermediate_size
+    img, patch, pool = w['image'], w['patch'], w['pool']
+    grid = [img[1 + k] // patch[k] for k in range(3)]
+    n_patch = math.prod(grid)
+    Nv = n_patch + 1
+    Np = math.prod(g // p for g, p in zip(grid, pool))
+    L = 1 + (Np + 2) + 1 + w['text']
+    nl_v, nl_l = vc['num_hidden_layers'], cfg.num_hidden_layers
+    F_vit_lin = nl_v * 2 * Nv * (4 * d * d + 2 * d * f) + 2 * n_patch * (768 * patch[0]) * d
+    F_vit_attn = nl_v * 4 * Nv * Nv * d
+    F_glu = 2 * Np * (d * h + 3 * h * i)
+    F_lm_lin = nl_l * 2 * L * (4 * h * h + 3 * h * i)
+    F_lm_attn = nl_l * 2 * L * L * h
+    F_head = 2 * L * h * cfg.vocab_size
+    F_lora = 2 * L * 64 * ((h + 3 * h) + (h + h) + 3 * (h + i)) * nl_l + 2 * Nv * 64 * ((d + 3 * d) + (d + d) + 2 * (d + f)) * nl_v
+    # frozen linears: fwd + dgrad (x2); trainable linears / LoRA / lm_head / attention: x3; frozen SAM + iSAM: x2 each
+    total = 2 * (F_vit_lin + F_glu + F_lm_lin) + 3 * (F_head + F_lora + F_vit_attn + F_lm_attn)
+    if sam:
+        Ns = n_patch
+        F_sam = 12 * (2 * Ns * (4 * 768 ** 2 + 2 * 768 * 3072) + 4 * Ns * Ns * 768)
+        total += 2 * 2 * F_sam
+    return float(total)
+
+
+def build(workload: dict, device, depth_scale: float = 1.0):
+    from mmmm_amd.models.cogvlm.configuration_cogvlm import CogVLMConfig
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, MyPrecision, VisionArgs
+    from mmmm_amd.data.synthetic import SpecialTokens
+    from mmmm_amd.utils import apply_lora
+    cfg = CogVLMConfig()
+    if depth_scale != 1.0:
+        cfg.num_hidden_layers = max(1, int(cfg.num_hidden_layers * depth_scale))
+        cfg.vision_config['num_hidden_layers'] = max(1, int(cfg.vision_config['num_hidden_layers'] * depth_scale))
+    tok = SpecialTokens(base_vocab=32000)
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(device):
+        sam = isam = mask_loss = isam_loss = None
+        if workload['sam']:
+            torch.set_default_dtype(torch.float32)
+            from mmmm_amd.models.segvol import build_sam, build_instance_sam
+            from mmmm_amd.models.loss import DiceFocalLoss
+            from mmmm_amd.models.segvol.modeling.sam import InstanceSamLoss
+            sam = build_sam(patch_size=16, pos_embed_shape=(8, 32, 32))
+            isam = build_instance_sam(patch_size=16, num_instances=6, pos_embed_shape=(8, 32, 32))
+            mask_loss = DiceFocalLoss(dice_weight=2, focal_weight=2, focal_gamma=2)
+            isam_loss = InstanceSamLoss(use_neg_mask=False, box_l1_weight=5, box_giou_weight=2, disc_weight=2,
+                                        disc_focal_gamma=2, disc_focal_alpha=0.85)
+            torch.set_default_dtype(torch.bfloat16)
+        model = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(8, 32, 32), pt_pos_embed_shape=(35, 35), patch_size=16),
+                                      tokenizer=tok, sam=sam, mask_loss=mask_loss, isam=isam, isam_loss=isam_loss, config=cfg)
+    torch.set_default_dtype(torch.float32)
+    if workload['sam']:
+        model.vg_proj.float()
+    apply_lora(model, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.05, use_rslora=True))
+    with torch.no_grad():   # non-degenerate adapters / special embeddings (peft zero-inits B; a zero B hides the LoRA path)
+        g = torch.Generator(device=device).manual_seed(1234)
+        for n, p in model.named_parameters():
+            if 'lora_B' in n:
+                p.copy_(torch.randn(p.shape, device=device, generator=g, dtype=torch.float32) * 0.01)
+            if n.endswith(('boi', 'eoi', 'cls_embedding.weight', 'cls_pos_embed.weight', 'position_embedding.weight', 'position_embeddings.weight')):
+                p.copy_(torch.randn(p.shape, device=device, generator=g, dtype=torch.float32) * 0.02)
+    MyPrecision().convert_module(model)
+    model.train()
+    if sam is not None:
+        sam.eval(); isam.eval()
+    model.on_fit_start()
+    return model, tok
+
+
+def make_batch(workload: dict, tok, B: int, device, seed: int):
+    from mmmm_amd.data.synthetic import make_batch as mk
+    inst = [(i % 2 == 1) for i in range(B)] if workload['sam'] else [False] * B
+    return mk([workload['image']] * B, [workload['patch']] * B, [workload['pool']] * B, [workload['text']] * B, tok=tok,
+              seed=seed, grounding=workload['sam'], n_pairs=4, instance=inst, device=device)
+
+
+def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
+    """The CPU oracle (oracle/vividmed.py, pinned against the reference) timed on the host cores on a bounded sample:
+    ONE true-width decoder layer + ONE true-width ViT layer + lm_head/CE, forward+backward, for one image of the
+    workload; extrapolated linearly in depth (32 / 63 layers). Reported baseline, not a target."""
+    from oracle import vividmed as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    vc = cfg.vision_config
+    ocfg = O.Cfg(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=1,
+                 num_attention_heads=cfg.num_attention_heads,
+                 vision=O.VisionCfg(hidden_size=vc['hidden_size'], num_heads=vc['num_heads'], num_hidden_layers=1,
+                                    intermediate_size=vc['intermediate_size'], layer_norm_eps=vc['layer_norm_eps']))
+    img, patch, pool = workload['image'], workload['patch'], workload['pool']
+    grid = [img[1 + k] // patch[k] for k in range(3)]
+    Nv = math.prod(grid) + 1
+    Np = math.prod(g // p for g, p in zip(grid, pool))
+    L = 1 + (Np + 2) + 1 + workload['text']
+    h, i, d, f = cfg.hidden_size, cfg.intermediate_size, vc['hidden_size'], vc['intermediate_size']
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02
+    sd = {}
+    pre = 'model.layers.0'
+    for e in ('vision', 'language'):
+        sd[f'{pre}.self_attn.{e}_expert_query_key_value.weight'] = r(3 * h, h)
+        sd[f'{pre}.self_attn.{e}_expert_dense.weight'] = r(h, h)
+        for nm, (o, ii) in dict(gate_proj=(i, h), up_proj=(i, h), down_proj=(h, i)).items():
+            sd[f'{pre}.mlp.{e}_mlp.{nm}.weight'] = r(o, ii)
+    sd[f'{pre}.input_layernorm.weight'] = torch.ones(h)
+    sd[f'{pre}.post_attention_layernorm.weight'] = torch.ones(h)
+    vp = 'v.0'
+    sd.update({f'{vp}.attention.query_key_value.weight': r(3 * d, d), f'{vp}.attention.query_key_value.bias': torch.zeros(3 * d),
+               f'{vp}.attention.dense.weight': r(d, d), f'{vp}.attention.dense.bias': torch.zeros(d),
+               f'{vp}.mlp.fc1.weight': r(f, d), f'{vp}.mlp.fc1.bias': torch.zeros(f), f'{vp}.mlp.fc2.weight': r(d, f),
+               f'{vp}.mlp.fc2.bias': torch.zeros(d), f'{vp}.input_layernorm.weight': torch.ones(d), f'{vp}.input_layernorm.bias': torch.zeros(d),
+               f'{vp}.post_attention_layernorm.weight': torch.ones(d), f'{vp}.post_attention_layernorm.bias': torch.zeros(d)})
+    sd['lm_head.weight'] = r(cfg.vocab_size, h)
+    tt = torch.zeros(1, L, dtype=torch.long)
+    tt[0, 1:1 + Np + 2] = 1
+    pos = torch.arange(L)[None]
+    am = torch.ones(1, L, dtype=torch.bool)
+    cos, sin = O.rope_tables(h // cfg.num_attention_heads, L, torch.float32)
+
+    def t_lm():
+        x = r(1, L, h).requires_grad_()
+        y = O.decoder_layer(sd, ocfg, pre, x, tt, pos, am, cos, sin)
+        y.sum().backward()
+
+    def t_vit():
+        x = r(Nv, d).requires_grad_()
+        O.vit_layer(sd, ocfg, vp, x, [Nv]).sum().backward()
+
+    def t_head():
+        x = r(L, h).requires_grad_()
+        lg = torch.nn.functional.linear(x, sd['lm_head.weight']).float()
+        O.weighted_ce(lg, torch.randint(0, cfg.vocab_size, (L,), generator=g), torch.ones(L)).backward()
+
+    def clock(fn):
+        fn()  # warm
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    a, b, c = clock(t_lm), clock(t_vit), clock(t_head)
+    per_image = cfg.num_hidden_layers * a + vc['num_hidden_layers'] * b + c
+    return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': (f'oracle fp32 fwd+bwd of 1 true-width decoder layer (L={L}) {a:.2f}s, 1 true-width ViT layer (Nv={Nv}) {b:.2f}s, '
+                       f'lm_head+CE {c:.2f}s on 1 image; extrapolated x{cfg.num_hidden_layers}/x{vc["num_hidden_layers"]} layers '
+                       f'(grounding heads not included)')}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
+    ap.add_argument('--depth-scale', type=float, default=1.0, help='debug only: <1 shrinks depth and invalidates the number')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the VividMed hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    from mmmm_amd import kernels as K, hip
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    w = WORKLOADS[args.workload]
+    model, tok = build(w, device, args.depth_scale)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    ddp = BucketedGradAllReduce(trainable, world_size=world)
+    opt = torch.optim.AdamW(trainable, lr=5e-5, weight_decay=0.01, fused=True)
+    batch = make_batch(w, tok, args.batch, device, seed=rank)      # resident in HBM before timing
+
+    def step():
+        ddp.zero_grad()
+        loss = model.training_step(batch)
+        loss.backward()
+        ddp.finish()
+        torch.nn.utils.clip_grad_norm_(trainable, 1.0, foreach=True)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    use_events = not args.no_kernel_events
+    if use_events:
+        K.prof_reset()
+        K.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if use_events:
+        K.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        value = images / dt
+        fl_sample = train_flops_per_sample(w, model.config, w['sam'])
+        out = {
+            'metric': 'train images/sec/node', 'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
+                       'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05',
+                       'gradient_checkpointing': True, 'optimizer': 'AdamW(fused) + clip 1.0', 'depth_scale': args.depth_scale},
+            'loss': loss_v,
+            'model_tflops_per_image': fl_sample / 1e12,
+            'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,
+        }
+        if use_events:
+            ms, fl, n = K.prof_collect(hip.PROF_GEMM_BF16)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+                               'launches': n, 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * 1e-3 / dt,
+                               'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over every launch of the timed region / summed HIP-event durations'}
+            ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)
+            if n_a:
+                out['attention'] = {'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12, 'launches': n_a, 'kernel_time_share': ms_a * 1e-3 / dt}
+            ms_f, fl_f, n_f = K.prof_collect(hip.PROF_GEMM_F32)
+            if n_f:
+                out['gemm_f32'] = {'achieved_tflops': fl_f / (ms_f * 1e-3) / 1e12, 'launches': n_f, 'kernel_time_share': ms_f * 1e-3 / dt}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(w, model.config)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
