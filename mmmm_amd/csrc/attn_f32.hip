@@ -1,6 +1,383 @@
-// fp32 attention for the fp32 islands (SAM ViT-B encoder, two-way transformer). See attn_f32 section of DESIGN.md.
+// fp32 attention for the fp32 islands of VividMed (`sam`, `isam_model`: reference mmmm.py:137-138):
+//   image_encoder.py:126-136   SAM ViT-B self-attention, packed var-len, head_dim 64
+//   transformer.py:224-239     two-way transformer: token self-attention (head_dim 96), token->image and
+//                              image->token cross-attention (head_dim 48), tiny Lq or tiny Lk
+// Exact f32 arithmetic on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, guide §3 "FP32-input MFMA"), same
+// transposed-score structure as attn_bf16.hip: S^T[kv][q] = K·Q^T puts the query on the lane, so softmax
+// statistics are lane-local and the accumulator registers of S^T are directly the B operand of
+// O^T[d][q] += V^T·P^T (one f32 per lane per k-step: no packing, no transposed LDS reads).
 #include "vm_common.hpp"
-extern "C" {
-int vm_attn_fwd_f32(const vm_attn_f32_args* a, void* stream) { (void)a; (void)stream; return VM_ERR_UNSUPPORTED; }
-int vm_attn_bwd_f32(const vm_attn_f32_args* a, void* stream) { (void)a; (void)stream; return VM_ERR_UNSUPPORTED; }
+
+extern "C" int vm_prof_begin_(int kind, void* stream, void** tok);
+extern "C" int vm_prof_end_(int kind, void* stream, void* tok, double flops);
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct AP {
+  const float* q; const float* k; const float* v; float* out;
+  int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;
+  float* lse;
+  int Bn, Lq, Lk, n_heads;
+  float scale;
+  const int32_t* cu;
+  const float* dout; int64_t do_bs, do_ls;
+  float* dq; float* dk; float* dv;
+  float* delta;
+};
+
+struct Seq { int64_t qo, ko, vo, oo, doo; int lq, lk, stat0; };
+
+// per-(batch or sequence) base offsets and lengths
+__device__ __forceinline__ Seq seq_of(const AP& p, int b) {
+  Seq s;
+  if (p.cu) {
+    const int s0 = p.cu[b], s1 = p.cu[b + 1];
+    s.lq = s.lk = s1 - s0;
+    s.qo = (int64_t)s0 * p.q_ls; s.ko = (int64_t)s0 * p.k_ls; s.vo = (int64_t)s0 * p.v_ls;
+    s.oo = (int64_t)s0 * p.o_ls; s.doo = (int64_t)s0 * p.do_ls;
+    s.stat0 = s0;
+  } else {
+    s.lq = p.Lq; s.lk = p.Lk;
+    s.qo = (int64_t)b * p.q_bs; s.ko = (int64_t)b * p.k_bs; s.vo = (int64_t)b * p.v_bs;
+    s.oo = (int64_t)b * p.o_bs; s.doo = (int64_t)b * p.do_bs;
+    s.stat0 = b * p.Lq;
+  }
+  return s;
 }
+// statistics (lse, delta) are stored [H][total_q] with total_q = cu[n] or Bn*Lq
+__device__ __forceinline__ int64_t stat_idx(const AP& p, int head, int stat0, int pos) {
+  const int64_t total = p.cu ? (int64_t)p.cu[p.Bn] : (int64_t)p.Bn * p.Lq;
+  return (int64_t)head * total + stat0 + pos;
+}
+
+// Stage ROWS x HD floats of a [pos][H][HD] operand into LDS with pitch PITCH (odd => conflict-free column reads).
+template <int HD, int HDP, int ROWS, int PITCH>
+__device__ __forceinline__ void stage(const float* base, int64_t ls, int head, int pos0, int len, float* tile, int tid) {
+  constexpr int PER_ROW = HDP / 4;
+  for (int c = tid; c < ROWS * PER_ROW; c += 256) {
+    const int row = c / PER_ROW, ch = c % PER_ROW;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    const int pos = pos0 + row;
+    if (pos < len && ch * 4 < HD) v = *reinterpret_cast<const f32x4_t*>(base + (int64_t)pos * ls + head * HD + ch * 4);
+    float* d = tile + row * PITCH + ch * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+}
+
+// ----------------------------------------------------------------------------- forward
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int NB = HDP / 32;
+  constexpr int KS = HD / 2;            // k-steps of the 32x32x2 MFMA over the head dimension
+  constexpr int PITCH = HDP + 1;
+  __shared__ float sK[32 * PITCH];
+  __shared__ float sV[32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int head = blockIdx.y;
+  const Seq sq = seq_of(p, blockIdx.z);
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= sq.lq) return;
+  const int qpos = q0 + wave * 32 + (lane & 31);
+  const bool qvalid = qpos < sq.lq;
+  const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
+  float qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = qvalid ? qrow[2 * s + h] : 0.f;
+
+  f32x16_t o[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = p.scale * LOG2E;
+  const int nt = (sq.lk + 31) / 32;
+  for (int t = 0; t < nt; ++t) {
+    const int kv0 = t * 32;
+    __syncthreads();
+    stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
+    stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    __syncthreads();
+    f32x16_t sa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kvpos = kv0 + acc_row(r, h);
+      float x = sa[r] * sc;
+      x = kvpos < sq.lk ? x : NEG_BIG;
+      sa[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float e = exp2f(sa[r] - m_new); sa[r] = e; rs += e; }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], o[b], 0, 0, 0);
+    }
+  }
+  if (!qvalid) return;
+  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (h == 0 && p.lse) p.lse[stat_idx(p, head, sq.stat0, qpos)] = (m_run + log2f(l_run)) * LN2;
+  float* orow = p.out + sq.oo + (int64_t)qpos * p.o_ls + head * HD;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * b + 8 * g + 4 * h;
+      if (d < HD) *reinterpret_cast<f32x4_t*>(orow + d) =
+          (f32x4_t){o[b][4 * g] * inv_l, o[b][4 * g + 1] * inv_l, o[b][4 * g + 2] * inv_l, o[b][4 * g + 3] * inv_l};
+    }
+}
+
+// ----------------------------------------------------------------------------- delta
+template <int HD>
+__global__ __launch_bounds__(256) void attn_f32_delta_k(const AP p) {
+  const int lane = threadIdx.x & 63;
+  const int head = blockIdx.y;
+  const Seq sq = seq_of(p, blockIdx.z);
+  const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= sq.lq) return;
+  const float* a = p.dout + sq.doo + (int64_t)pos * p.do_ls + head * HD;
+  const float* b = p.out + sq.oo + (int64_t)pos * p.o_ls + head * HD;
+  float acc = 0.f;
+  for (int d = lane; d < HD; d += 64) acc += a[d] * b[d];
+  acc = wave_sum(acc);
+  if (lane == 0) p.delta[stat_idx(p, head, sq.stat0, pos)] = acc;
+}
+
+// ----------------------------------------------------------------------------- backward dQ
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int NB = HDP / 32;
+  constexpr int KS = HD / 2;
+  constexpr int PITCH = HDP + 1;
+  __shared__ float sK[32 * PITCH];
+  __shared__ float sV[32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int head = blockIdx.y;
+  const Seq sq = seq_of(p, blockIdx.z);
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= sq.lq) return;
+  const int qpos = q0 + wave * 32 + (lane & 31);
+  const bool qvalid = qpos < sq.lq;
+  const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
+  const float* dorow = p.dout + sq.doo + (int64_t)(qvalid ? qpos : 0) * p.do_ls + head * HD;
+  float qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) { qf[s] = qvalid ? qrow[2 * s + h] : 0.f; dof[s] = qvalid ? dorow[2 * s + h] : 0.f; }
+  const float lse2 = qvalid ? p.lse[stat_idx(p, head, sq.stat0, qpos)] * LOG2E : 0.f;
+  const float dlt = qvalid ? p.delta[stat_idx(p, head, sq.stat0, qpos)] : 0.f;
+  const float sc = p.scale * LOG2E;
+  f32x16_t dq[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
+  const int nt = (sq.lk + 31) / 32;
+  for (int t = 0; t < nt; ++t) {
+    const int kv0 = t * 32;
+    __syncthreads();
+    stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
+    stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    __syncthreads();
+    f32x16_t sa, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * PITCH + 2 * s + h], dof[s], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kvpos = kv0 + acc_row(r, h);
+      const float pr = (kvpos < sq.lk && qvalid) ? exp2f(sa[r] * sc - lse2) : 0.f;
+      sa[r] = pr * (dp[r] - dlt) * p.scale;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dq[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dq[b], 0, 0, 0);
+  }
+  if (!qvalid) return;
+  float* drow = p.dq + sq.qo + (int64_t)qpos * p.q_ls + head * HD;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * b + 8 * g + 4 * h;
+      if (d < HD) *reinterpret_cast<f32x4_t*>(drow + d) = (f32x4_t){dq[b][4 * g], dq[b][4 * g + 1], dq[b][4 * g + 2], dq[b][4 * g + 3]};
+    }
+}
+
+// ----------------------------------------------------------------------------- backward dK, dV
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int NB = HDP / 32;
+  constexpr int KS = HD / 2;
+  constexpr int PITCH = HDP + 1;
+  __shared__ float sQ[32 * PITCH];
+  __shared__ float sDO[32 * PITCH];
+  __shared__ float sLse[32];
+  __shared__ float sDlt[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int head = blockIdx.y;
+  const Seq sq = seq_of(p, blockIdx.z);
+  const int k0 = blockIdx.x * 128;
+  if (k0 >= sq.lk) return;
+  const int kpos = k0 + wave * 32 + (lane & 31);
+  const bool kvalid = kpos < sq.lk;
+  const float* krow = p.k + sq.ko + (int64_t)(kvalid ? kpos : 0) * p.k_ls + head * HD;
+  const float* vrow = p.v + sq.vo + (int64_t)(kvalid ? kpos : 0) * p.v_ls + head * HD;
+  float kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) { kf[s] = kvalid ? krow[2 * s + h] : 0.f; vf[s] = kvalid ? vrow[2 * s + h] : 0.f; }
+  const float sc = p.scale * LOG2E;
+  f32x16_t dk[NB], dv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+  const int nt = (sq.lq + 31) / 32;
+  for (int t = 0; t < nt; ++t) {
+    const int qq0 = t * 32;
+    __syncthreads();
+    stage<HD, HDP, 32, PITCH>(p.q + sq.qo, p.q_ls, head, qq0, sq.lq, sQ, tid);
+    stage<HD, HDP, 32, PITCH>(p.dout + sq.doo, p.do_ls, head, qq0, sq.lq, sDO, tid);
+    if (tid < 32) {
+      const int qp = qq0 + tid;
+      sLse[tid] = qp < sq.lq ? p.lse[stat_idx(p, head, sq.stat0, qp)] * LOG2E : 0.f;
+      sDlt[tid] = qp < sq.lq ? p.delta[stat_idx(p, head, sq.stat0, qp)] : 0.f;
+    }
+    __syncthreads();
+    f32x16_t sa, dp, pa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[(lane & 31) * PITCH + 2 * s + h], kf[s], sa, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[(lane & 31) * PITCH + 2 * s + h], vf[s], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, h);
+      const bool vis = kvalid && (qq0 + qi) < sq.lq;
+      const float pr = vis ? exp2f(sa[r] * sc - sLse[qi]) : 0.f;
+      pa[r] = pr;
+      sa[r] = pr * (dp[r] - sDlt[qi]) * p.scale;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dv[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], pa[r], dv[b], 0, 0, 0);
+        dk[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dk[b], 0, 0, 0);
+      }
+  }
+  if (!kvalid) return;
+  float* dkrow = p.dk + sq.ko + (int64_t)kpos * p.k_ls + head * HD;
+  float* dvrow = p.dv + sq.vo + (int64_t)kpos * p.v_ls + head * HD;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * b + 8 * g + 4 * h;
+      if (d < HD) {
+        *reinterpret_cast<f32x4_t*>(dkrow + d) = (f32x4_t){dk[b][4 * g], dk[b][4 * g + 1], dk[b][4 * g + 2], dk[b][4 * g + 3]};
+        *reinterpret_cast<f32x4_t*>(dvrow + d) = (f32x4_t){dv[b][4 * g], dv[b][4 * g + 1], dv[b][4 * g + 2], dv[b][4 * g + 3]};
+      }
+    }
+}
+
+AP to_ap(const vm_attn_f32_args* a) {
+  AP p;
+  p.q = a->q; p.k = a->k; p.v = a->v; p.out = a->out;
+  p.q_bs = a->q_bs; p.q_ls = a->q_ls; p.k_bs = a->k_bs; p.k_ls = a->k_ls; p.v_bs = a->v_bs; p.v_ls = a->v_ls;
+  p.o_bs = a->o_bs; p.o_ls = a->o_ls;
+  p.lse = a->lse; p.Bn = a->cu_seqlens ? a->n_seq : a->Bn; p.Lq = a->Lq; p.Lk = a->Lk; p.n_heads = a->n_heads;
+  p.scale = a->scale; p.cu = a->cu_seqlens;
+  p.dout = a->dout; p.do_bs = a->do_bs; p.do_ls = a->do_ls;
+  p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
+  return p;
+}
+
+bool ok(const vm_attn_f32_args* a) {
+  if (!a || !a->q || !a->k || !a->v || !a->out || !a->lse) return false;
+  if (a->n_heads <= 0 || a->Lq <= 0 || a->Lk <= 0) return false;
+  if (a->cu_seqlens ? a->n_seq <= 0 : a->Bn <= 0) return false;
+  if (a->q_ls % 4 || a->k_ls % 4 || a->v_ls % 4 || a->o_ls % 4) return false;
+  return true;
+}
+
+}  // namespace
+
+#define F32_DISPATCH_HD(hd, ...)                                  \
+  switch (hd) {                                                   \
+    case 128: { constexpr int HD = 128; __VA_ARGS__; break; }     \
+    case 96:  { constexpr int HD = 96;  __VA_ARGS__; break; }     \
+    case 64:  { constexpr int HD = 64;  __VA_ARGS__; break; }     \
+    case 48:  { constexpr int HD = 48;  __VA_ARGS__; break; }     \
+    case 32:  { constexpr int HD = 32;  __VA_ARGS__; break; }     \
+    case 16:  { constexpr int HD = 16;  __VA_ARGS__; break; }     \
+    case 8:   { constexpr int HD = 8;   __VA_ARGS__; break; }     \
+    default: return VM_ERR_UNSUPPORTED;                           \
+  }
+
+extern "C" {
+
+int vm_attn_fwd_f32(const vm_attn_f32_args* a, void* stream) {
+  if (!ok(a)) return VM_ERR_BAD_ARG;
+  AP p = to_ap(a);
+  dim3 grid((a->Lq + 127) / 128, a->n_heads, p.Bn);
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
+  F32_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_f32_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  vm_prof_end_(VM_PROF_ATTN, stream, tok, 4.0 * a->Lq * (double)a->Lk * a->head_dim * a->n_heads * p.Bn);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_attn_bwd_f32(const vm_attn_f32_args* a, void* stream) {
+  if (!ok(a) || !a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return VM_ERR_BAD_ARG;
+  if (a->do_ls % 4) return VM_ERR_BAD_ARG;
+  AP p = to_ap(a);
+  dim3 gq((a->Lq + 127) / 128, a->n_heads, p.Bn), gk((a->Lk + 127) / 128, a->n_heads, p.Bn);
+  dim3 gd((a->Lq + 3) / 4, a->n_heads, p.Bn);
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
+  F32_DISPATCH_HD(a->head_dim,
+                  hipLaunchKernelGGL(attn_f32_delta_k<HD>, gd, dim3(256), 0, (hipStream_t)stream, p);
+                  hipLaunchKernelGGL(attn_f32_dq_k<HD>, gq, dim3(256), 0, (hipStream_t)stream, p);
+                  hipLaunchKernelGGL(attn_f32_dkv_k<HD>, gk, dim3(256), 0, (hipStream_t)stream, p));
+  vm_prof_end_(VM_PROF_ATTN, stream, tok, 10.0 * a->Lq * (double)a->Lk * a->head_dim * a->n_heads * p.Bn);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+}  // extern "C"

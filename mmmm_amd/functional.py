@@ -33,6 +33,22 @@ def _t(w: torch.Tensor) -> torch.Tensor:
     return K.transpose(w.detach())
 
 
+def _ktile(dtype: torch.dtype) -> int:
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def _padk(*ts):
+    """zero-pad the contraction (last) dimension up to the GEMM K-tile. Only small odd-shaped layers of the fp32
+    grounding heads (box / disc heads, hyper-network outputs) and tiny test models ever take this path."""
+    k = ts[0].shape[-1]
+    kt = _ktile(ts[0].dtype)
+    if k % kt == 0:
+        return ts if len(ts) > 1 else ts[0]
+    pad = kt - k % kt
+    out = tuple(None if t is None else torch.nn.functional.pad(t, (0, pad)) for t in ts)
+    return out if len(out) > 1 else out[0]
+
+
 class _Linear(Function):
     """y = act(x W^T + s·(drop(x) A^T) B^T + b) + residual, optionally per row segment.
 
@@ -46,9 +62,11 @@ class _Linear(Function):
         t = None
         if lora:
             xd = K.dropout(x, meta.drop_p, meta.drop_seed) if meta.drop_p > 0 else x
-            t = K.gemm(xd, A0, w1=A1 if meta.gated else None, counts=counts if meta.gated else None)
+            xdp, A0p, A1p = _padk(xd, A0, A1)
+            t = K.gemm(xdp, A0p, w1=A1p if meta.gated else None, counts=counts if meta.gated else None)
+        xp, W0p, W1p = _padk(x, W0, W1)
         y = K.gemm(
-            x, W0, w1=W1 if meta.gated else None,
+            xp, W0p, w1=W1p if meta.gated else None,
             a2=t, b2=B0 if lora else None, b2_1=B1 if (lora and meta.gated) else None, alpha2=meta.lora_scale if lora else 1.0,
             bias=b0, bias1=b1 if meta.gated else None, residual=residual,
             counts=counts if meta.gated else None, act=meta.act, out_dtype=meta.out_dtype,
@@ -73,11 +91,13 @@ class _Linear(Function):
         g = [None] * 14
         u = None
         if lora and (need[1] or need[7] or need[12]):
-            u = K.gemm(dy, _t(B0), w1=_t(B1) if gated else None, counts=cnt)          # [M, r] = dy · B
+            dyp, b0t, b1t = _padk(dy, _t(B0), _t(B1) if gated else None)
+            u = K.gemm(dyp, b0t, w1=b1t, counts=cnt)                                  # [M, r] = dy · B
         if need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None
-            g[1] = K.gemm(dy, wt0, w1=wt1, a2=u, b2=_t(A0) if lora else None, b2_1=_t(A1) if (lora and gated) else None,
+            dyp, wt0, wt1 = _padk(dy, wt0, wt1)
+            g[1] = K.gemm(dyp, wt0, w1=wt1, a2=u, b2=_t(A0) if lora else None, b2_1=_t(A1) if (lora and gated) else None,
                           alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
         if ctx.has_residual and need[2]:
             g[2] = dy
@@ -268,6 +288,30 @@ def attention(qkv, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, sca
               row_of_pos=None, total_pos_max: int | None = None):
     """qkv: [rows, 3*H*hd] packed (q | k | v) -> [rows, H*hd]"""
     return _Attention.apply(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
+
+
+# ----------------------------------------------------------------------------- fp32 attention (SAM islands)
+class _AttentionF32(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen):
+        q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+        out, lse = K.attn_f32_fwd(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+        ctx.save_for_backward(q, k, v, out, lse, cu_seqlens)
+        ctx.cfg = (n_heads, head_dim, scale, max_seqlen)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse, cu = ctx.saved_tensors
+        n_heads, head_dim, scale, max_seqlen = ctx.cfg
+        dq, dk, dv = K.attn_f32_bwd(q, k, v, out, lse, dout, n_heads, head_dim, scale, cu, max_seqlen)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention_f32(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen=None):
+    """dense batched [Bn, L, H*hd] or packed var-len [T, H*hd] (+cu_seqlens) fp32 attention"""
+    return _AttentionF32.apply(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
 
 
 # ----------------------------------------------------------------------------- rows: embedding / gather / scatter

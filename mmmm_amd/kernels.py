@@ -49,7 +49,11 @@ def gemm(
     if out_dtype is None:
         out_dtype = a.dtype
     if out is None:
-        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+        al = 8 if out_dtype == torch.bfloat16 else 4
+        Np = (N + al - 1) // al * al                 # keep ldc aligned for the vector stores of the epilogue
+        out = torch.empty(M, Np, dtype=out_dtype, device=a.device)
+        if Np != N:
+            out = out[:, :N]
     g = hip.GemmArgs()
     g.A, g.lda = ptr(a), _ld(a)
     g.B, g.B_1, g.ldb = ptr(w), ptr(w1), _ld(w)
@@ -354,3 +358,52 @@ def prof_collect(kind: int):
     ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
     hip.call('vm_prof_collect', kind, C.addressof(ms), C.addressof(fl), C.addressof(n))
     return ms.value, fl.value, n.value
+
+
+# ------------------------------------------------------------------ attention (fp32 islands)
+def _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens):
+    """q [Bn, Lq, H*hd] / k,v [Bn, Lk, H*hd] (strided views allowed, inner dim contiguous); or packed
+    [T, H*hd] with cu_seqlens (self-attention)."""
+    a = hip.AttnF32Args()
+    a.q, a.k, a.v, a.out = ptr(q), ptr(k), ptr(v), ptr(out)
+    if cu_seqlens is not None:
+        a.q_ls, a.k_ls, a.v_ls, a.o_ls = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        a.Bn, a.Lq, a.Lk = 1, q.shape[0], k.shape[0]
+        a.cu_seqlens, a.n_seq = ptr(cu_seqlens), cu_seqlens.numel() - 1
+    else:
+        a.q_bs, a.q_ls, a.k_bs, a.k_ls = q.stride(0), q.stride(1), k.stride(0), k.stride(1)
+        a.v_bs, a.v_ls, a.o_bs, a.o_ls = v.stride(0), v.stride(1), out.stride(0), out.stride(1)
+        a.Bn, a.Lq, a.Lk = q.shape[0], q.shape[1], k.shape[1]
+    a.lse = ptr(lse)
+    a.n_heads, a.head_dim, a.scale = n_heads, head_dim, scale
+    return a
+
+
+def attn_f32_fwd(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None):
+    assert q.dtype == torch.float32 and q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
+    out = torch.empty(*q.shape[:-1], n_heads * head_dim, dtype=q.dtype, device=q.device)
+    n_q = q.shape[0] if cu_seqlens is not None else q.shape[0] * q.shape[1]
+    lse = torch.empty(n_heads, n_q, dtype=torch.float32, device=q.device)
+    a = _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens)
+    if cu_seqlens is not None and max_seqlen is not None:
+        a.Lq = a.Lk = max_seqlen
+    hip.call('vm_attn_fwd_f32', C.addressof(a), stream())
+    return out, lse
+
+
+def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None):
+    dout = _c(dout)
+    dq, dk, dv = torch.zeros_like(q, memory_format=torch.contiguous_format), torch.zeros_like(k, memory_format=torch.contiguous_format), \
+        torch.zeros_like(v, memory_format=torch.contiguous_format)
+    q, k, v = _c(q), _c(k), _c(v)
+    a = _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens)
+    if cu_seqlens is not None and max_seqlen is not None:
+        a.Lq = a.Lk = max_seqlen
+    if cu_seqlens is not None:
+        a.do_ls = dout.stride(0)
+    else:
+        a.do_bs, a.do_ls = dout.stride(0), dout.stride(1)
+    delta = torch.empty_like(lse)
+    a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
+    hip.call('vm_attn_bwd_f32', C.addressof(a), stream())
+    return dq, dk, dv

@@ -1,0 +1,98 @@
+"""SAM ViT-B image encoder (reference segvol/modeling/image_encoder.py; pre-LN blocks with MONAI's parameter names
+`blocks.N.{norm1, attn.{qkv,out_proj}, norm2, mlp.{linear1,linear2}}`), fp32, all images of the batch packed into
+one var-len sequence; attention on vm_attn_*_f32 (head_dim 64)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+from .... import functional as Fh
+from ...cogvlm.visual import ParameterWrapper
+from ...lora import Linear
+from ...resample import Downsample, resample
+
+
+class PatchEmbeddingBlock(nn.Module):
+    def __init__(self, in_channels: int, patch_size, pos_embed_shape: tuple, hidden_size: int, num_heads: int, dropout_rate: float = 0.0,
+                 pt_in_channels=None, pt_patch_size=None, pt_pos_embed_shape=None):
+        super().__init__()
+        self.proj = Downsample(in_channels, hidden_size, patch_size)
+        self.position_embeddings = ParameterWrapper(torch.zeros(1, hidden_size, *pos_embed_shape))
+        self.pt_in_channels, self.pt_patch_size, self.pt_pos_embed_shape = pt_in_channels, pt_patch_size, pt_pos_embed_shape
+
+    def forward(self, image_list, patch_size_list):
+        xs, shapes = [], []
+        for image, patch in zip(image_list, patch_size_list):
+            x, shape = self.proj(image, patch)
+            pos = resample(self.position_embeddings.weight, shape)
+            xs.append(x + pos[0].flatten(1).t().to(x.dtype))
+            shapes.append(shape)
+        return torch.cat(xs, dim=0), shapes, [t.shape[0] for t in xs]
+
+
+class SABlock(nn.Module):
+    def __init__(self, hidden_size: int, num_heads: int, qkv_bias: bool = False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = hidden_size // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.out_proj = Linear(hidden_size, hidden_size)
+        self.qkv = Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
+
+    def forward(self, x, cu, max_len):
+        qkv = self.qkv(x)
+        C = self.num_heads * self.head_dim
+        out = Fh.attention_f32(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.num_heads, self.head_dim, self.scale, cu, max_len)
+        return self.out_proj(out)
+
+
+class MLPBlock(nn.Module):
+    def __init__(self, hidden_size: int, mlp_dim: int):
+        super().__init__()
+        self.linear1 = Linear(hidden_size, mlp_dim)
+        self.linear2 = Linear(mlp_dim, hidden_size)
+
+    def forward(self, x):
+        return self.linear2(Fh.gelu(self.linear1(x)))
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, hidden_size: int, mlp_dim: int, num_heads: int, qkv_bias: bool = False):
+        super().__init__()
+        self.mlp = MLPBlock(hidden_size, mlp_dim)
+        self.norm1 = nn.LayerNorm(hidden_size)
+        self.attn = SABlock(hidden_size, num_heads, qkv_bias)
+        self.norm2 = nn.LayerNorm(hidden_size)
+
+    def forward(self, x, cu, max_len):
+        n1, n2 = self.norm1, self.norm2
+        x = x + self.attn(Fh.layer_norm(x, n1.weight, n1.bias, n1.eps), cu, max_len)
+        return x + self.mlp(Fh.layer_norm(x, n2.weight, n2.bias, n2.eps))
+
+
+class ImageEncoderViT(nn.Module):
+    def __init__(self, in_channels: int, patch_size, pos_embed_shape: tuple, hidden_size: int = 768, mlp_dim: int = 3072, num_layers: int = 12,
+                 num_heads: int = 12, dropout_rate: float = 0.0, qkv_bias: bool = False, pt_in_channels=None, pt_patch_size=None,
+                 pt_pos_embed_shape=None):
+        super().__init__()
+        self.patch_embedding = PatchEmbeddingBlock(in_channels, patch_size, pos_embed_shape, hidden_size, num_heads, dropout_rate,
+                                                   pt_in_channels, pt_patch_size, pt_pos_embed_shape)
+        self.blocks = nn.ModuleList([TransformerBlock(hidden_size, mlp_dim, num_heads, qkv_bias) for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(hidden_size)
+        self.gradient_checkpointing = False
+
+    def forward(self, image: list[torch.Tensor], patch_size: list[tuple]):
+        """-> per image: channel-last tokens [Ns, C] and the (d, h, w) grid"""
+        x, shapes, lens = self.patch_embedding(image, patch_size)
+        cu_host = [0]
+        for n in lens:
+            cu_host.append(cu_host[-1] + n)
+        cu = torch.tensor(cu_host, dtype=torch.int32, device=x.device)
+        for blk in self.blocks:
+            if self.gradient_checkpointing and self.training and x.requires_grad:
+                x = checkpoint(blk, x, cu, max(lens), use_reentrant=False, preserve_rng_state=False)
+            else:
+                x = blk(x, cu, max(lens))
+        x = Fh.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return [x[cu_host[i]:cu_host[i + 1]] for i in range(len(lens))], shapes

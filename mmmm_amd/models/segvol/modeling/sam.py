@@ -1,0 +1,206 @@
+"""Sam / InstanceSam grounding heads and InstanceSamLoss (reference segvol/modeling/sam.py) on the fp32 HIP kernels.
+
+Differences in execution, not in results: the image encoder runs once over the packed batch; the mask decoder works
+channel-last; Hungarian matching stays on the host (scipy, as the reference) but all cost matrices of a sample are
+computed on the device and fetched with ONE device->host copy instead of one per target (reference sam.py:243)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .... import functional as Fh
+from ...lora import Linear
+from ...loss import DiceFocalLoss, sigmoid_focal_loss
+from .image_encoder import ImageEncoderViT
+from .mask_decoder import MaskDecoder
+from .prompt_encoder import PromptEncoder
+
+MATCH_NEGATIVE, MATCH_UNCERTAIN = -1, -2
+
+
+class Sam(nn.Module):
+    def __init__(self, image_encoder: ImageEncoderViT, prompt_encoder: PromptEncoder, mask_decoder: MaskDecoder):
+        super().__init__()
+        self.image_encoder, self.prompt_encoder, self.mask_decoder = image_encoder, prompt_encoder, mask_decoder
+
+    @property
+    def prompt_dim(self):
+        return self.prompt_encoder.embed_dim
+
+    @property
+    def mask_embed_dim(self):
+        return self.mask_decoder.transformer_dim
+
+    @property
+    def num_mask_tokens(self):
+        return self.mask_decoder.num_mask_tokens
+
+    def _predict_masks(self, text_embedding, image_tokens, grid, patch_size_z, need_masks=True):
+        sparse, dense = self.prompt_encoder(grid, text_embedding=text_embedding)
+        return self.mask_decoder(image_tokens, self.prompt_encoder.get_dense_pe(grid), sparse.to(text_embedding.dtype), dense,
+                                 text_embedding, patch_size_z, grid, need_masks=need_masks)
+
+    def forward(self, image: list[torch.Tensor], patch_size: list[tuple], text_embedding: list[torch.Tensor]):
+        """-> per sample [P, D, H, W] semantic mask logits at image resolution (reference :72-87)"""
+        tokens, grids = self.image_encoder(image, patch_size)
+        outs = []
+        for i in range(len(image)):
+            low, _ = self._predict_masks(text_embedding[i], tokens[i], grids[i], patch_size[i][0])
+            low = low[:, 0]
+            outs.append(F.interpolate(low[None], image[i].shape[1:], mode='trilinear')[0] if low.shape[0] > 0 else low)
+        return outs
+
+
+@dataclass
+class InstanceSamOutput:
+    masks_logits: list
+    masks_logits_low_res: list
+    boxes: list
+    disc_logit: list
+
+
+class InstanceSam(Sam):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        c = self.mask_embed_dim
+        self.box_head = nn.Sequential(Linear(c, c), nn.ReLU(inplace=True), Linear(c, c), nn.ReLU(inplace=True), Linear(c, 6))
+        self.disc_head = nn.Sequential(Linear(c, c), nn.ReLU(inplace=True), Linear(c, 1))
+
+    def forward(self, image, patch_size, text_embedding, need_masks: bool = False):
+        """training_step only consumes boxes / disc_logit (mmmm.py:214-219): the mask branch of the instance decoder
+        (frozen by _freeze_sam_unused) is skipped unless need_masks=True."""
+        tokens, grids = self.image_encoder(image, patch_size)
+        lows, boxes, discs = [], [], []
+        for i in range(len(image)):
+            low, emb = self._predict_masks(text_embedding[i], tokens[i], grids[i], patch_size[i][0], need_masks=need_masks)
+            x = self.box_head[4](Fh.relu(self.box_head[2](Fh.relu(self.box_head[0](emb)))))
+            boxes.append(x.float().sigmoid())
+            discs.append(self.disc_head[2](Fh.relu(self.disc_head[0](emb[:, 1:].contiguous())))[..., 0])
+            lows.append(low)
+        masks = [F.interpolate(m, image[i].shape[1:], mode='trilinear') if m is not None else None for i, m in enumerate(lows)]
+        return InstanceSamOutput(masks, lows, boxes, discs)
+
+
+def box_cs_to_cc(b: torch.Tensor) -> torch.Tensor:
+    c, s = b[..., :3], b[..., 3:]
+    return torch.cat([c - s / 2, c + s / 2], -1)
+
+
+def box_pair_giou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """monai.data.box_utils.box_pair_giou [external]: fp32, eps-regularised denominators"""
+    eps = torch.finfo(torch.float32).eps
+    b1, b2 = b1.float(), b2.float()
+    a1 = (b1[..., 3:] - b1[..., :3]).prod(-1)
+    a2 = (b2[..., 3:] - b2[..., :3]).prod(-1)
+    inter = (torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+    union = a1 + a2 - inter
+    iou = inter / (union + eps)
+    enc = (torch.max(b1[..., 3:], b2[..., 3:]) - torch.min(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+    return iou - (enc - union) / (enc + eps)
+
+
+class InstanceSamLoss(nn.Module):
+    def __init__(self, *, mask_loss: DiceFocalLoss | None = None, use_neg_mask: bool, box_l1_weight: float, box_giou_weight: float,
+                 disc_weight: float, disc_focal_gamma: float, disc_focal_alpha: float | None = None, match_ce: bool = True):
+        super().__init__()
+        self.mask_loss = mask_loss
+        self.use_neg_mask = use_neg_mask
+        self.box_l1_weight, self.box_giou_weight, self.disc_weight = box_l1_weight, box_giou_weight, disc_weight
+        self.disc_focal_gamma, self.disc_focal_alpha = disc_focal_gamma, disc_focal_alpha
+        self.match_ce = match_ce
+
+    def box_loss(self, input, target, reduce_batch: bool = True, return_dict: bool = False):
+        l1 = F.l1_loss(input, target) if reduce_batch else F.l1_loss(input, target, reduction='none').mean(dim=-1)
+        giou = box_pair_giou(box_cs_to_cc(input), box_cs_to_cc(target))
+        if reduce_batch:
+            giou = giou.mean()
+        giou = 1 - giou
+        total = self.box_l1_weight * l1 + self.box_giou_weight * giou
+        return {'l1': l1, 'giou': giou, 'total': total} if return_dict else total
+
+    def disc_loss(self, input, label, reduce_batch: bool = True, return_dict: bool = False, alpha: bool = True):
+        if isinstance(label, bool):
+            label = (torch.ones_like if label else torch.zeros_like)(input)
+        d = sigmoid_focal_loss(input, label, self.disc_focal_gamma, self.disc_focal_alpha if alpha else None)
+        if reduce_batch:
+            d = d.mean()
+        total = self.disc_weight * d
+        return {f'focal-{self.disc_focal_gamma:.1f}': d, 'total': total} if return_dict else total
+
+    @torch.no_grad()
+    def _match_all(self, boxes_reg, disc_logit, boxes_label, index_offsets_host: list[tuple[int, int]]):
+        """box-only Hungarian matching of every target of one sample (reference _match_instances :178-250,
+        masks_label None, num_uncertain 0). Cost matrices are built on the device, copied to the host once."""
+        from scipy.optimize import linear_sum_assignment
+        nt, nq = disc_logit.shape
+        costs, metas = [], []
+        prob = disc_logit.sigmoid()
+        for i, (s, e) in enumerate(index_offsets_host):
+            npos = e - s
+            nneg = max(nq - npos, 0)
+            if nq == nneg:
+                metas.append(None)
+                continue
+            if self.match_ce:
+                cp, cn = self.disc_weight * (1 - prob[i]), self.disc_weight * prob[i]
+            else:
+                cp = self.disc_loss(disc_logit[i], True, reduce_batch=False)
+                cn = self.disc_loss(disc_logit[i], False, reduce_batch=False)
+            disc_cost = torch.cat([cp[:, None].expand(nq, npos), cn[:, None].expand(nq, nneg)], dim=1)
+            a = boxes_reg[i][:, None].expand(nq, npos, 6).reshape(-1, 6)
+            b = boxes_label[s:e][None].expand(nq, npos, 6).reshape(-1, 6)
+            pair = self.box_loss(a, b, reduce_batch=False).reshape(nq, npos)
+            cost = torch.cat([pair, disc_cost.new_zeros(nq, nneg)], dim=1) + disc_cost
+            metas.append((len(costs), npos, cost.shape[1], s))
+            costs.append(cost.float())
+        match = torch.full((nt, nq), MATCH_NEGATIVE, dtype=torch.int64)
+        if costs:
+            width = max(c.shape[1] for c in costs)
+            host = torch.stack([F.pad(c, (0, width - c.shape[1])) for c in costs]).cpu().numpy()   # ONE device->host transfer
+            for i, meta in enumerate(metas):
+                if meta is None:
+                    continue
+                j, npos, ncol, off = meta
+                row, col = linear_sum_assignment(host[j][:, :ncol])
+                m = torch.empty(nq, dtype=torch.int64)
+                m[torch.as_tensor(row)] = torch.as_tensor(col)
+                m[m >= npos] = MATCH_NEGATIVE
+                m[m >= 0] += off
+                match[i] = m
+        return match.to(disc_logit.device)
+
+    def compute_loss(self, masks_logits, masks_logits_ds, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets):
+        """reference :252-361, branch used by the training step (no instance masks)"""
+        if masks_label is not None:
+            raise NotImplementedError('instance segmentation labels are not supported yet (reference mmmm.py:239-241)')
+        nt = disc_logit.shape[0]
+        assert nt == index_offsets.shape[0]
+        loss = 0 * disc_logit.sum()
+        log = {}
+        if nt > 0:
+            boxes_reg = boxes_reg[:, 1:]
+            disc_logit = disc_logit.float()
+            offs = [tuple(x) for x in index_offsets.tolist()]
+            match = self._match_all(boxes_reg, disc_logit, boxes_label, offs)
+            pos, neg, certain = match >= 0, match == MATCH_NEGATIVE, match != MATCH_UNCERTAIN
+            d = self.disc_loss(disc_logit[certain], pos[certain], return_dict=True)
+            loss = loss + d.pop('total')
+            log.update({f'instance-disc-{k}': v for k, v in d.items()})
+            n_pos = int(pos.sum())
+            if n_pos > 0:
+                with torch.no_grad():
+                    d = self.disc_loss(disc_logit[pos], True, return_dict=True, alpha=False)
+                    d.pop('total')
+                    log.update({f'instance-disc-pos-{k}': v for k, v in d.items()})
+                d = self.box_loss(boxes_reg[pos], boxes_label[match[pos]], return_dict=True)
+                loss = loss + d.pop('total')
+                log.update({f'instance-box-{k}': v for k, v in d.items()})
+            if n_pos < match.numel():
+                with torch.no_grad():
+                    d = self.disc_loss(disc_logit[neg], False, return_dict=True, alpha=False)
+                    d.pop('total')
+                    log.update({f'instance-disc-neg-{k}': v for k, v in d.items()})
+        return loss, log
