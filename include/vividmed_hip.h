@@ -58,6 +58,7 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
 #define VM_PROF_GEMM_BF16 0
 #define VM_PROF_GEMM_F32 1
 #define VM_PROF_ATTN 2
+#define VM_PROF_LORA 3 /* vm_lora_down + vm_gemm_tn_bf16 */
 
 /* ------------------------------------------------------------------------
  * Token routing metadata.
@@ -122,6 +123,25 @@ typedef struct vm_gemm_args {
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);
+
+/* LoRA down-projection (peft lora.Linear, conf/lora.yaml r = 64): t[M,64] = drop(x)[M,K] · A[64,K]^T with the
+ * inverted dropout of lora_dropout fused on the activation fragment ((seed, row*K+col) hash, same mask as
+ * vm_dropout). Also computes u = dy · B in the backward (A = B^T). Optional two row segments (gated experts):
+ * rows [0,split) use A0, rows [split,M) use A1; split / M from counts_dev when non-NULL. R must be 64, K % 128 == 0. */
+int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
+                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed, void* stream);
+
+/* Row-contraction ("TN") bf16 GEMM for weight gradients: C[P,Q] = alpha * X[M,P]^T · drop(Y)[M,Q] contracted over
+ * token rows — dB = dy^T t, dA = u^T drop(x), dW = dy^T x of peft lora.Linear / trainable nn.Linear. Operands stay
+ * row-major as stored (transposed LDS reads feed the MFMA); no transposed activation copies.
+ * Row range: all rows (bounded by nrows_dev when non-NULL), or with counts_dev: segment 0 = [0,counts[0]),
+ * segment 1 = [counts[0],counts[1]), segment -1 = [0,counts[1]).
+ * splits > 1 distributes the row range over `splits` workgroups per tile that accumulate with fp32 atomics into C
+ * (must be fp32 and zero-filled) — used when P*Q alone gives too few tiles to fill 256 CUs.
+ * drop_p > 0 applies the inverted dropout mask of element (row, col) of a [*, drop_cols] tensor to Y. */
+int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ldy, int Q, void* C, int64_t ldc,
+                    int out_dtype, int M, const int32_t* counts_dev, int segment, const int32_t* nrows_dev, int splits,
+                    float alpha, float drop_p, uint64_t drop_seed, int drop_cols, void* stream);
 
 /* fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fma chain). Same NT form and
  * argument struct (all dtypes f32; K % 32 == 0, K2 % 32 == 0, ld % 4 == 0). Used by the fp32 islands

@@ -11,44 +11,16 @@
 // V tile. O^T keeps the query on the lane too, so rescaling by the running max is a per-lane scalar.
 // The backward is two kernels of the same shape (dQ: query-stationary; dK/dV: key-stationary), no atomics.
 #include "vm_common.hpp"
+#include "vm_tile.hpp"
 
 extern "C" int vm_prof_begin_(int kind, void* stream, void** tok);
 extern "C" int vm_prof_end_(int kind, void* stream, void* tok, double flops);
 
 namespace {
 
-constexpr int ROWB = 256;            // LDS row pitch in bytes (128 bf16; head dims < 128 are zero padded)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
-
-// XOR swizzle of the 16-byte chunk index, conflict-free for both ds_read_b128 row reads and
-// ds_read_b64_tr_b16 transposed reads of a 256-byte-row tile (guide T10 image (b)).
-__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
-
-// A/B operand fragment of a 32x32x16 MFMA read along rows: lane -> row r0+(lane&31), k = 16*s + 8*(lane>>5) + 0..7
-__device__ __forceinline__ bf16x8_t frag_row(const char* tile, int r0, int s, int lane) {
-  return *reinterpret_cast<const bf16x8_t*>(tile + tile_off(r0 + (lane & 31), 2 * s + (lane >> 5)));
-}
-
-// Transposed fragment: operand element j of lane half h is tile[row = rbase + 8*(j>>2) + 4*h + (j&3)][col = 32*b + (lane&31)]
-// (the k order in which an accumulator tile's registers 8s..8s+7 appear as the other operand).
-__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int rbase, int b, int lane) {
-  const int i = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
-  const int q4 = i >> 2, pp = i & 3;
-  const int chunk = 4 * b + 2 * g + (pp >> 1);
-  const int rowA = rbase + 4 * h + q4, rowB = rowA + 8;
-  const char* a = tile + tile_off(rowA, chunk) + ((pp & 1) << 3);
-  const char* c = tile + tile_off(rowB, chunk) + ((pp & 1) << 3);
-  u16x4_t lo = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a)));
-  u16x4_t hi = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(c)));
-  u16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, r);
-}
 
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16 operand fragment
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int s) {

@@ -218,10 +218,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
         for (int j = 0; j < 4; ++j) {
           const int m = row0 + wm * 64 + j * 16 + frow;
           const int n = n0 + wn * 64 + i * 16 + fq * 4;
+          // n is a multiple of 4 and N % 4 == 0 is required with dropout: the 4 registers share one hash group
+          const uint64_t hsh = drop ? vm_hash4(p.drop_seed, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2) : 0ull;
+          const unsigned thr = vm_drop_threshold(p.drop_p);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float s = a2;
-            if (drop) s = vm_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + r), p.drop_p) ? a2 * inv_keep : 0.f;
+            if (drop) s = vm_keep_bits(hsh, r, thr) ? a2 * inv_keep : 0.f;
             acc[i][j][r] *= s;
           }
         }
@@ -290,7 +293,7 @@ struct ProfRec { hipEvent_t a, b; double flops; };
 struct ProfState {
   std::mutex mu;
   bool on = false;
-  std::vector<ProfRec> recs[3];
+  std::vector<ProfRec> recs[4];
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 ProfState& prof() { static ProfState s; return s; }
@@ -346,7 +349,7 @@ int vm_prof_reset(void) {
 }
 
 int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, int64_t* launches_host) {
-  if (kind < 0 || kind > 2) return VM_ERR_BAD_ARG;
+  if (kind < 0 || kind > 3) return VM_ERR_BAD_ARG;
   ProfState& s = prof();
   std::lock_guard<std::mutex> lk(s.mu);
   double ms = 0, fl = 0;
@@ -372,6 +375,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (a->out_dtype != VM_BF16 && a->out_dtype != VM_F32) return VM_ERR_BAD_ARG;
   if (esz == 4 && a->out_dtype != VM_F32) return VM_ERR_UNSUPPORTED;
   if (a->ldc % 4) return VM_ERR_BAD_ARG;
+  if (a->drop_p > 0.f && (a->N % 4)) return VM_ERR_BAD_ARG;
   const bool segmented = a->counts_dev != nullptr || a->split >= 0;
   if (segmented && !a->B_1) return VM_ERR_BAD_ARG;
   // 32-bit buffer offsets inside one tile: 128 rows * pitch must fit

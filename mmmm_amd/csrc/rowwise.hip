@@ -7,7 +7,6 @@ namespace {
 
 constexpr int ROW_WAVES = 4;          // waves (= rows in flight) per workgroup
 constexpr int ROW_THREADS = ROW_WAVES * 64;
-constexpr int MAX_PARTIAL = 64;       // fp32 partials per lane for dw/db accumulation (cols <= 4096)
 
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::vec_t ldv(const T* p) {
@@ -49,64 +48,67 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_fwd_k(
   }
 }
 
+// dx only (one wave per row, full grid); the parameter gradients are column sums done by norm_bwd_dwdb_k
 template <typename T>
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
-    const float* __restrict__ rstd, T* __restrict__ dx, float* __restrict__ dw_accum,
-    int rows, int cols, const int32_t* nrows_dev) {
+    const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols, const int32_t* nrows_dev) {
   constexpr int V = Elem<T>::VEC;
-  constexpr int NP = MAX_PARTIAL / V;  // passes supported
   if (nrows_dev) rows = min(rows, *nrows_dev);
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
-  float part[MAX_PARTIAL];
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  const T* dyr = dy + (int64_t)row * cols;
+  T* dxr = dx + (int64_t)row * cols;
+  const float r = rstd[row];
+  float dot = 0.f;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
 #pragma unroll
-  for (int i = 0; i < MAX_PARTIAL; ++i) part[i] = 0.f;
-  const float inv_cols = 1.0f / (float)cols;
-  for (int row = blockIdx.x * ROW_WAVES + wid; row < rows; row += gridDim.x * ROW_WAVES) {
-    const T* xr = x + (int64_t)row * cols;
-    const T* dyr = dy + (int64_t)row * cols;
-    T* dxr = dx + (int64_t)row * cols;
-    const float r = rstd[row];
-    float dot = 0.f;
+    for (int i = 0; i < V; ++i) dot += Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) * (Elem<T>::ld(xv[i]) * r);
+  }
+  dot = wave_sum(dot) / (float)cols;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int c = (p * 64 + lane) * V;
-      if (c < cols) {
-        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const float xh = Elem<T>::ld(xv[i]) * r, g = Elem<T>::ld(gv[i]);
-          dot += Elem<T>::ld(wv[i]) * g * xh;
-          part[p * V + i] += g * xh;
-        }
-      }
+    for (int i = 0; i < V; ++i) {
+      const float xh = Elem<T>::ld(xv[i]) * r;
+      o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) - xh * dot));
     }
-    dot = wave_sum(dot) * inv_cols;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int c = (p * 64 + lane) * V;
-      if (c < cols) {
-        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
-        typename Elem<T>::vec_t o;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const float xh = Elem<T>::ld(xv[i]) * r;
-          o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) - xh * dot));
-        }
-        stv<T>(dxr + c, o);
-      }
+    stv<T>(dxr + c, o);
+  }
+}
+
+// dw[c] += sum_r dy[r,c] * xhat[r,c] ; db[c] += sum_r dy[r,c]   with xhat = (x - mean[r]) * rstd[r]  (mean == NULL -> 0).
+// Grid: (cols/64 column groups) x (row chunks of 128); lane = column, the 4 waves of a block interleave rows.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_dwdb_k(
+    const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ dw_accum, float* __restrict__ db_accum, int rows, int cols, const int32_t* nrows_dev) {
+  __shared__ float red[2][4][64];
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * 128;
+  const int r1 = min(r0 + 128, rows);
+  float aw = 0.f, ab = 0.f;
+  if (c < cols) {
+    for (int r = r0 + wid; r < r1; r += 4) {
+      const float g = Elem<T>::ld(dy[(int64_t)r * cols + c]);
+      const float mu = mean ? mean[r] : 0.f;
+      aw += g * ((Elem<T>::ld(x[(int64_t)r * cols + c]) - mu) * rstd[r]);
+      ab += g;
     }
   }
-  if (dw_accum) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int c = (p * 64 + lane) * V;
-      if (c < cols) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) atomicAdd(dw_accum + c + i, part[p * V + i]);
-      }
-    }
+  red[0][wid][lane] = aw; red[1][wid][lane] = ab;
+  __syncthreads();
+  if (wid == 0 && c < cols && r0 < rows) {
+    aw = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    ab = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    if (dw_accum) atomicAdd(dw_accum + c, aw);
+    if (db_accum) atomicAdd(db_accum + c, ab);
   }
 }
 
@@ -161,66 +163,38 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_k(
 template <typename T>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_k(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
-    const float* __restrict__ mean, const float* __restrict__ rstd,
-    T* __restrict__ dx, float* __restrict__ dw_accum, float* __restrict__ db_accum,
-    int rows, int cols) {
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols) {
   constexpr int V = Elem<T>::VEC;
-  constexpr int NP = MAX_PARTIAL / V;
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
-  float pw[MAX_PARTIAL], pb[MAX_PARTIAL];
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  const T* dyr = dy + (int64_t)row * cols;
+  T* dxr = dx + (int64_t)row * cols;
+  const float mu = mean[row], r = rstd[row];
+  float s1 = 0.f, s2 = 0.f;  // sum(w*dy), sum(w*dy*xhat)
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
+    typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
 #pragma unroll
-  for (int i = 0; i < MAX_PARTIAL; ++i) { pw[i] = 0.f; pb[i] = 0.f; }
-  const float inv_cols = 1.0f / (float)cols;
-  for (int row = blockIdx.x * ROW_WAVES + wid; row < rows; row += gridDim.x * ROW_WAVES) {
-    const T* xr = x + (int64_t)row * cols;
-    const T* dyr = dy + (int64_t)row * cols;
-    T* dxr = dx + (int64_t)row * cols;
-    const float mu = mean[row], r = rstd[row];
-    float s1 = 0.f, s2 = 0.f;  // sum(w*dy), sum(w*dy*xhat)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int c = (p * 64 + lane) * V;
-      if (c < cols) {
-        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
-        typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
-          const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
-          s1 += wg; s2 += wg * xh;
-          pw[p * V + i] += g * xh; pb[p * V + i] += g;
-        }
-      }
-    }
-    s1 = wave_sum(s1) * inv_cols; s2 = wave_sum(s2) * inv_cols;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int c = (p * 64 + lane) * V;
-      if (c < cols) {
-        auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
-        typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
-        typename Elem<T>::vec_t o;
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
-          const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
-          o[i] = Elem<T>::st(r * (wg - s1 - xh * s2));
-        }
-        stv<T>(dxr + c, o);
-      }
+    for (int i = 0; i < V; ++i) {
+      const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
+      const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+      s1 += wg; s2 += wg * xh;
     }
   }
+  s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
+  for (int c = lane * V; c < cols; c += 64 * V) {
+    auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
+    typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o;
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int c = (p * 64 + lane) * V;
-    if (c < cols) {
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        if (dw_accum) atomicAdd(dw_accum + c + i, pw[p * V + i]);
-        if (db_accum) atomicAdd(db_accum + c + i, pb[p * V + i]);
-      }
+    for (int i = 0; i < V; ++i) {
+      const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
+      const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+      o[i] = Elem<T>::st(r * (wg - s1 - xh * s2));
     }
+    stv<T>(dxr + c, o);
   }
 }
 
@@ -285,6 +259,12 @@ __global__ __launch_bounds__(256) void ew_k(const T* __restrict__ a, const T* __
     typename Elem<T>::vec_t bv;
     if (OP == EW_SILU_MUL_F || OP == EW_GELU_B || OP == EW_RELU_B || OP == EW_ADD) bv = ldv<T>(b + i * V);
     typename Elem<T>::vec_t o;
+    uint64_t h0 = 0, h1 = 0;
+    if (OP == EW_DROPOUT) {   // V = 4 (f32): one hash group; V = 8 (bf16): two
+      h0 = vm_hash4(seed, (uint64_t)(i * V) >> 2);
+      if (V == 8) h1 = vm_hash4(seed, ((uint64_t)(i * V) >> 2) + 1);
+    }
+    const unsigned thr = vm_drop_threshold(p);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const float x = Elem<T>::ld(av[j]);
@@ -297,7 +277,7 @@ __global__ __launch_bounds__(256) void ew_k(const T* __restrict__ a, const T* __
       else if (OP == EW_GELU_B) r = gelu_erf_grad(x) * Elem<T>::ld(bv[j]);
       else if (OP == EW_RELU_B) r = x > 0.f ? Elem<T>::ld(bv[j]) : 0.f;
       else if (OP == EW_ADD) r = x + Elem<T>::ld(bv[j]);
-      else /* EW_DROPOUT */ r = vm_keep(seed, (uint64_t)(i * V + j), p) ? x * inv_keep : 0.f;
+      else /* EW_DROPOUT */ r = vm_keep_bits(j < 4 ? h0 : h1, j & 3, thr) ? x * inv_keep : 0.f;
       o[j] = Elem<T>::st(r);
     }
     stv<T>(y + i * V, o);
@@ -579,12 +559,15 @@ int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rs
                    int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream) {
   if (rows <= 0) return VM_OK;
   const int vec = dtype == VM_BF16 ? 8 : 4;
-  if (cols % vec || cols > 64 * MAX_PARTIAL) return VM_ERR_UNSUPPORTED;
-  int blocks = (rows + ROW_WAVES - 1) / ROW_WAVES;
-  if (blocks > 256) blocks = 256;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_bwd_k<T>, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)w, (const T*)dy, rstd, (T*)dx, dw_accum, rows, cols,
-                                           nrows_dev));
+  if (cols % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                                    (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev);
+                 if (dw_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                                  (const T*)dy, (const float*)nullptr, rstd, dw_accum, (float*)nullptr, rows, cols,
+                                                  nrows_dev));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }
@@ -606,12 +589,15 @@ int vm_layernorm_bwd(const void* x, const void* w, const void* dy, const float* 
                      float* dw_accum, float* db_accum, int rows, int cols, int dtype, void* stream) {
   if (rows <= 0) return VM_OK;
   const int vec = dtype == VM_BF16 ? 8 : 4;
-  if (cols % vec || cols > 64 * MAX_PARTIAL) return VM_ERR_UNSUPPORTED;
-  int blocks = (rows + ROW_WAVES - 1) / ROW_WAVES;
-  if (blocks > 256) blocks = 256;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_bwd_k<T>, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)w, (const T*)dy, mean, rstd, (T*)dx, dw_accum,
-                                           db_accum, rows, cols));
+  if (cols % vec) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                                    (const T*)dy, mean, rstd, (T*)dx, rows, cols);
+                 if (dw_accum || db_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream,
+                                                              (const T*)x, (const T*)dy, mean, rstd, dw_accum, db_accum, rows, cols,
+                                                              (const int32_t*)nullptr));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

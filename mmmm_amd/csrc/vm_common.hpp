@@ -78,16 +78,22 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// Counter-based RNG for dropout masks: splitmix64 of (seed, element index).
-// Returns true when the element is KEPT. Identical on every recompute.
-__device__ __forceinline__ bool vm_keep(uint64_t seed, uint64_t idx, float p) {
-  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+// Counter-based RNG for dropout masks: one splitmix64 hash serves FOUR consecutive elements (16 bits each), so a
+// lane that owns 4 or 8 consecutive elements hashes once or twice. keep(idx) is a pure function of (seed, idx, p):
+// the standalone dropout kernel, the LoRA down-projection, the GEMM dgrad epilogue and the TN weight-gradient
+// kernel all regenerate the same mask (forward, checkpoint recompute and backward agree).
+__device__ __forceinline__ uint64_t vm_hash4(uint64_t seed, uint64_t group) {
+  uint64_t z = seed + (group + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  // 24 random bits -> uniform [0,1)
-  float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-  return u >= p;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned vm_drop_threshold(float p) { return (unsigned)(p * 65536.0f); }
+__device__ __forceinline__ bool vm_keep_bits(uint64_t h, int sub, unsigned thr) {
+  return ((unsigned)(h >> (16 * sub)) & 0xFFFFu) >= thr;
+}
+__device__ __forceinline__ bool vm_keep(uint64_t seed, uint64_t idx, float p) {
+  return vm_keep_bits(vm_hash4(seed, idx >> 2), (int)(idx & 3), vm_drop_threshold(p));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {

@@ -49,6 +49,15 @@ def _padk(*ts):
     return out if len(out) > 1 else out[0]
 
 
+def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
+    """t = drop(x) @ A^T : fused skinny kernel when the shape allows, else dropout + padded NT GEMM"""
+    if K.lora_down_supported(x, A0):
+        return K.lora_down(x, A0, A1 if gated else None, counts=counts if gated else None, drop_p=drop_p, drop_seed=seed)
+    xd = K.dropout(x, drop_p, seed) if drop_p > 0 else x
+    xdp, A0p, A1p = _padk(xd, A0, A1)
+    return K.gemm(xdp, A0p, w1=A1p if gated else None, counts=counts if gated else None)
+
+
 class _Linear(Function):
     """y = act(x W^T + s·(drop(x) A^T) B^T + b) + residual, optionally per row segment.
 
@@ -61,9 +70,7 @@ class _Linear(Function):
         lora = meta.lora_scale != 0.0 and A0 is not None
         t = None
         if lora:
-            xd = K.dropout(x, meta.drop_p, meta.drop_seed) if meta.drop_p > 0 else x
-            xdp, A0p, A1p = _padk(xd, A0, A1)
-            t = K.gemm(xdp, A0p, w1=A1p if meta.gated else None, counts=counts if meta.gated else None)
+            t = _lora_project(x, A0, A1, meta.gated, counts, meta.drop_p, meta.drop_seed)
         xp, W0p, W1p = _padk(x, W0, W1)
         y = K.gemm(
             xp, W0p, w1=W1p if meta.gated else None,
@@ -91,8 +98,7 @@ class _Linear(Function):
         g = [None] * 14
         u = None
         if lora and (need[1] or need[7] or need[12]):
-            dyp, b0t, b1t = _padk(dy, _t(B0), _t(B1) if gated else None)
-            u = K.gemm(dyp, b0t, w1=b1t, counts=cnt)                                  # [M, r] = dy · B
+            u = _lora_project(dy, _t(B0), _t(B1) if gated else None, gated, counts)       # [M, r] = dy · B
         if need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None
@@ -101,37 +107,40 @@ class _Linear(Function):
                           alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
         if ctx.has_residual and need[2]:
             g[2] = dy
-        # parameter gradients: contraction over tokens -> K-contiguous transposes feed the same NT kernel
+        # parameter gradients contract over token rows
         experts = ((0, W0, b0, A0, B0, 4), (1, W1, b1, A1, B1, 9)) if gated else ((0, W0, b0, A0, B0, 4),)
-        need_lora_grad = lora and any(need[i] for i in (7, 8, 12, 13))
-        need_w_grad = any(need[i] for i in (4, 9))
-        if need_lora_grad or need_w_grad or need[6] or need[11]:
-            xd = None
-            if need_lora_grad:
-                xd = K.dropout(x, meta.drop_p, meta.drop_seed) if meta.drop_p > 0 else x
-            for e, W, b, A, B, base in experts:
+        tn_ok = x.dtype == torch.bfloat16 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+        for e, W, b, A, B, base in experts:
+            seg = e if gated else -1
+            if tn_ok:
+                # row-contraction MFMA kernel on the row-major activations as they are: no transposed copies
+                if need[base]:
+                    g[base] = K.gemm_tn(dy, x, counts=cnt, segment=seg)
+                if lora and need[base + 4]:                                   # dB = s · dy^T · t
+                    g[base + 4] = K.gemm_tn(dy, t, counts=cnt, segment=seg, alpha=s)
+                if lora and need[base + 3]:                                   # dA = s · u^T · drop(x)
+                    g[base + 3] = K.gemm_tn(u, x, counts=cnt, segment=seg, alpha=s, drop_p=meta.drop_p, drop_seed=meta.drop_seed)
+            else:
+                # fp32 islands / odd shapes: K-contiguous transposes feed the NT kernel
                 def tr(z):
                     return K.transpose_segment(z, counts, e) if gated else K.transpose(z, pad_to=64)
-                dyT = None
-                if need[base] or (lora and need[base + 4]):
-                    dyT = tr(dy)
-                if need[base]:                                   # full weight gradient
+                dyT = tr(dy) if (need[base] or (lora and need[base + 4])) else None
+                if need[base]:
                     g[base] = K.gemm(dyT, tr(x))
-                if b is not None and need[base + 2]:
-                    if gated:
-                        ones = torch.ones(1, dyT.shape[1], dtype=dyT.dtype, device=dyT.device) if dyT is not None else None
-                        if dyT is None:
-                            dyT = tr(dy)
-                            ones = torch.ones(1, dyT.shape[1], dtype=dyT.dtype, device=dyT.device)
-                        g[base + 2] = K.gemm(dyT, ones.expand(8, -1).contiguous())[:, 0].to(b.dtype)
-                    else:
-                        g[base + 2] = K.colsum(dy).to(b.dtype)
-                if lora and need[base + 4]:                       # dB = s · dy^T · t
+                if lora and need[base + 4]:
                     dB = K.gemm(dyT, tr(t))
                     g[base + 4] = dB if s == 1.0 else dB * s
-                if lora and need[base + 3]:                       # dA = s · u^T · drop(x)
+                if lora and need[base + 3]:
+                    xd = K.dropout(x, meta.drop_p, meta.drop_seed) if meta.drop_p > 0 else x
                     dA = K.gemm(tr(u), tr(xd))
                     g[base + 3] = dA if s == 1.0 else dA * s
+            if b is not None and need[base + 2]:
+                if gated:
+                    dyT = K.transpose_segment(dy, counts, e)
+                    ones = torch.ones(8, dyT.shape[1], dtype=dyT.dtype, device=dyT.device)
+                    g[base + 2] = K.gemm(dyT, ones)[:, 0].to(b.dtype)
+                else:
+                    g[base + 2] = K.colsum(dy).to(b.dtype)
         return tuple(g)
 
 

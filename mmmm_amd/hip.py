@@ -17,7 +17,7 @@ HEADER_PATH = Path(__file__).resolve().parents[1] / 'include' / 'vividmed_hip.h'
 
 VM_BF16, VM_F32 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-PROF_GEMM_BF16, PROF_GEMM_F32, PROF_ATTN = 0, 1, 2
+PROF_GEMM_BF16, PROF_GEMM_F32, PROF_ATTN, PROF_LORA = 0, 1, 2, 3
 
 
 class HipExtensionMissing(RuntimeError):

@@ -115,6 +115,46 @@ def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
     return out
 
 
+def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None, *, counts: torch.Tensor | None = None,
+              split: int = -1, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """t[M,64] = drop(x) @ A^T (bf16; rank 64; K % 128 == 0)"""
+    M, Kd = x.shape
+    t = torch.empty(M, A0.shape[0], dtype=x.dtype, device=x.device)
+    hip.call('vm_lora_down', ptr(x), _ld(x), ptr(A0), ptr(A1), _ld(A0), ptr(t), _ld(t), M, Kd, A0.shape[0], ptr(counts), split,
+             drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, stream())
+    return t
+
+
+def lora_down_supported(x: torch.Tensor, A: torch.Tensor) -> bool:
+    return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 128 == 0
+
+
+def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = None, segment: int = -1,
+            nrows: torch.Tensor | None = None, alpha: float = 1.0, drop_p: float = 0.0, drop_seed: int = 0,
+            out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """C[P,Q] = alpha * X[M,P]^T @ drop(Y)[M,Q], contraction over rows (all rows, or one routed segment)"""
+    assert X.dtype == torch.bfloat16 and Y.dtype == torch.bfloat16 and X.shape[0] == Y.shape[0]
+    M, P = X.shape
+    Q = Y.shape[1]
+    out_dtype = out_dtype or X.dtype
+    tiles = ((P + 127) // 128) * ((Q + 127) // 128)
+    splits = 1
+    if tiles < 128 and M >= 256:
+        splits = max(1, min(16, 256 // tiles, M // 128))
+    if splits > 1:
+        C32 = torch.zeros(P, Q, dtype=torch.float32, device=X.device)
+        hip.call('vm_gemm_tn_bf16', ptr(X), _ld(X), P, ptr(Y), _ld(Y), Q, ptr(C32), Q, VM_F32_, M, ptr(counts), segment, ptr(nrows),
+                 splits, alpha, drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, Y.shape[1], stream())
+        return C32 if out_dtype == torch.float32 else cast(C32, out_dtype)
+    Cc = torch.empty(P, Q, dtype=out_dtype, device=X.device)
+    hip.call('vm_gemm_tn_bf16', ptr(X), _ld(X), P, ptr(Y), _ld(Y), Q, ptr(Cc), Q, dtype_code(out_dtype), M, ptr(counts), segment,
+             ptr(nrows), 1, alpha, drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, Y.shape[1], stream())
+    return Cc
+
+
+VM_F32_ = hip.VM_F32
+
+
 # ------------------------------------------------------------------ norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tensor | None = None):
     x = _c(x)

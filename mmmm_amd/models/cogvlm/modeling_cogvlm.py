@@ -271,7 +271,7 @@ class _LMHeadCE(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dh = K.gemm(d, K.transpose(W.detach(), pad_to=64))              # K = padded vocab
         if ctx.needs_input_grad[1]:
-            dW = K.gemm(K.transpose(d[:, :V], pad_to=64), K.transpose(h, pad_to=64, nrows=nrows))
+            dW = K.gemm_tn(d[:, :V], h, nrows=nrows)
         return dh, dW, None, None, None
 
 

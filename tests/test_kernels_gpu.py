@@ -414,3 +414,61 @@ def test_attention_rare_rescale_branch(dev, K):
     out, _ = K.attn_fwd(q, k, v, cu_t, L, H, hd, 1.0, False)
     ref = _attn_ref(q.float().view(L, H, hd), k.float().view(L, H, hd), v.float().view(L, H, hd), [0, L], 1.0, False)
     assert rel_err(out.view(L, H, hd), ref) < 1e-2
+
+
+# ------------------------------------------------------------------ LoRA kernels
+@pytest.mark.parametrize('M,Kd', [(1, 128), (43, 384), (3648, 4096), (500, 1792)])
+def test_lora_down(dev, K, M, Kd):
+    x = torch.randn(M, Kd, device=dev).bfloat16()
+    A = (torch.randn(64, Kd, device=dev) / math.sqrt(Kd)).bfloat16()
+    t = K.lora_down(x, A)
+    assert rel_err(t, x.float() @ A.float().T) < 4e-3
+    # fused dropout == standalone dropout kernel followed by the projection
+    p, seed = 0.05, 77
+    t2 = K.lora_down(x, A, drop_p=p, drop_seed=seed)
+    xd = K.dropout(x, p, seed)
+    assert rel_err(t2, xd.float() @ A.float().T) < 4e-3
+    assert rel_err(t2, t) > 1e-2 or M * Kd < 1000
+
+
+@pytest.mark.parametrize('split', [0, 7, 16, 100, 257])
+def test_lora_down_two_segments(dev, K, split):
+    M, Kd = 257, 256
+    x = torch.randn(M, Kd, device=dev).bfloat16()
+    A0 = (torch.randn(64, Kd, device=dev) / 16).bfloat16()
+    A1 = (torch.randn(64, Kd, device=dev) / 16).bfloat16()
+    ref = torch.cat([x[:split].float() @ A0.float().T, x[split:].float() @ A1.float().T])
+    assert rel_err(K.lora_down(x, A0, A1, split=split), ref) < 4e-3
+    counts = torch.tensor([split, M, 0, 0], dtype=torch.int32, device=dev)
+    xb = torch.zeros(300, Kd, device=dev).bfloat16()
+    xb[:M] = x
+    assert rel_err(K.lora_down(xb, A0, A1, counts=counts)[:M], ref) < 4e-3
+
+
+@pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (100, 64, 384), (3648, 12288, 64), (3648, 64, 4096), (777, 200, 136), (3648, 32008, 256)])
+def test_gemm_tn(dev, K, M, P, Q):
+    X = torch.randn(M, P, device=dev).bfloat16()
+    Y = torch.randn(M, Q, device=dev).bfloat16()
+    ref = X.float().T @ Y.float()
+    out = K.gemm_tn(X, Y)
+    assert out.shape == (P, Q) and rel_err(out, ref) < 4e-3
+    out2 = K.gemm_tn(X, Y, alpha=0.5, out_dtype=torch.float32)
+    assert rel_err(out2, 0.5 * ref) < 3e-3 if True else None
+
+
+def test_gemm_tn_segments_and_dropout(dev, K):
+    M, P, Q = 517, 64, 256
+    X = torch.randn(640, P, device=dev).bfloat16()
+    Y = torch.randn(640, Q, device=dev).bfloat16()
+    counts = torch.tensor([200, M, 0, 0], dtype=torch.int32, device=dev)
+    r0 = X[:200].float().T @ Y[:200].float()
+    r1 = X[200:M].float().T @ Y[200:M].float()
+    assert rel_err(K.gemm_tn(X, Y, counts=counts, segment=0), r0) < 4e-3
+    assert rel_err(K.gemm_tn(X, Y, counts=counts, segment=1), r1) < 4e-3
+    assert rel_err(K.gemm_tn(X, Y, counts=counts, segment=-1), r0 + r1) < 4e-3
+    n = torch.tensor([M], dtype=torch.int32, device=dev)
+    assert rel_err(K.gemm_tn(X, Y, nrows=n), r0 + r1) < 4e-3
+    p, seed = 0.1, 4242
+    Yd = K.dropout(Y, p, seed)
+    got = K.gemm_tn(X, Y, counts=counts, segment=1, drop_p=p, drop_seed=seed)
+    assert rel_err(got, X[200:M].float().T @ Yd[200:M].float()) < 4e-3
