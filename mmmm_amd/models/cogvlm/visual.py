@@ -38,10 +38,13 @@ class PatchEmbedding(nn.Module):
         """-> packed tokens [sum Nv, C], cu_seqlens (host list), grid shapes (visual.py:59-77)"""
         xs, shapes = [], []
         cls = self.cls_embedding.weight + self.cls_pos_embed.weight
+        pos_cache: dict[tuple, torch.Tensor] = {}        # one resample per distinct grid, not per image
         for image, patch in zip(image_list, patch_size_list):
             x, shape = self.proj(image, patch)
-            pos = resample(self.position_embedding.weight, shape)            # [1, C, d, h, w]
-            x = x + pos[0].flatten(1).t().to(x.dtype)
+            if shape not in pos_cache:
+                pos = resample(self.position_embedding.weight, shape)        # [1, C, d, h, w]
+                pos_cache[shape] = pos[0].flatten(1).t().to(x.dtype)
+            x = x + pos_cache[shape]
             xs.append(torch.cat([cls.to(x.dtype), x], dim=0))
             shapes.append(shape)
         lens = [t.shape[0] for t in xs]

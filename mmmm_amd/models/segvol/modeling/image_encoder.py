@@ -23,10 +23,12 @@ class PatchEmbeddingBlock(nn.Module):
 
     def forward(self, image_list, patch_size_list):
         xs, shapes = [], []
+        pos_cache: dict[tuple, torch.Tensor] = {}
         for image, patch in zip(image_list, patch_size_list):
             x, shape = self.proj(image, patch)
-            pos = resample(self.position_embeddings.weight, shape)
-            xs.append(x + pos[0].flatten(1).t().to(x.dtype))
+            if shape not in pos_cache:
+                pos_cache[shape] = resample(self.position_embeddings.weight, shape)[0].flatten(1).t().to(x.dtype)
+            xs.append(x + pos_cache[shape])
             shapes.append(shape)
         return torch.cat(xs, dim=0), shapes, [t.shape[0] for t in xs]
 
