@@ -11,8 +11,10 @@
 // The weight is the MFMA "A" operand and the activation the "B" operand, so a lane's 4 accumulator
 // registers are 4 consecutive output columns n (8-byte / 16-byte stores).
 #include "vm_common.hpp"
+#include "gemm_common.hpp"
 #include <vector>
 #include <mutex>
+#include <cstdlib>
 
 namespace {
 
@@ -20,35 +22,6 @@ constexpr int BM = 128, BN = 128;
 constexpr int TILE_BYTES = BM * 128;          // 16 KiB per operand tile (128 rows x 128 B)
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // double buffer = 64 KiB
-constexpr int GROUP_M = 8;
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-struct GemmParams {
-  const char* A; int64_t lda;          // leading dimensions in ELEMENTS
-  const char* B0; const char* B1; int64_t ldb;
-  const char* A2; int64_t lda2;
-  const char* B2_0; const char* B2_1; int64_t ldb2;
-  int K2; float alpha2;
-  const void* bias0; const void* bias1;
-  const void* residual; int64_t ldr;
-  void* C; int64_t ldc;
-  int M, N, K;
-  const int32_t* counts_dev;
-  int split;
-  int act;
-  float drop_p; uint64_t drop_seed;
-  int tiles_m, tiles_n;
-};
-
-// Buffer resource from provably wave-uniform words (avoids hipcc's waterfall loops, guide T20).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, int64_t byte_off, int bytes) {
-  const uint64_t a = (uint64_t)(base + byte_off);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  const int n = __builtin_amdgcn_readfirstlane(bytes);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
-}
 
 // Issue the LDS-DMA loads of one 128x64 bf16 operand tile. `rsrc` covers the tile's valid rows
 // (rows past the end read as zero), `ld_bytes` is the row pitch, `koff` the byte offset of the K-tile.
@@ -75,35 +48,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- tile id: XCD-aware bijective remap, then grouped (GROUP_M) ordering
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int per_group = GROUP_M * p.tiles_n;
-  const int g = bid / per_group;
-  const int gm0 = g * GROUP_M;
-  const int gsz = min(GROUP_M, p.tiles_m - gm0);
-  const int tm = gm0 + (bid % per_group) % gsz;
-  const int tn = (bid % per_group) / gsz;
-
-  // ---- rows of this m-tile (device-side counts for the token-routed form)
-  int M = p.M, split = p.split;
-  if (p.counts_dev) {
-    split = __builtin_amdgcn_readfirstlane(p.counts_dev[0]);
-    M = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
-  }
-  int row0, nrows, seg = 0;
-  if (split < 0) {
-    row0 = tm * BM; nrows = min(BM, M - row0);
-  } else {
-    split = min(split, M);
-    const int t0 = (split + BM - 1) / BM;
-    if (tm < t0) { row0 = tm * BM; nrows = min(BM, split - row0); }
-    else { seg = 1; row0 = split + (tm - t0) * BM; nrows = min(BM, M - row0); }
-  }
+  int tm, tn;
+  gemm_tile_id(p, tm, tn);
+  int row0, nrows, seg;
+  gemm_tile_rows<BM>(p, tm, row0, nrows, seg);
   if (nrows <= 0) return;
   const int n0 = tn * BN;
   const int ncols = min(BN, p.N - n0);
@@ -207,27 +155,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s >> 2][s & 3], xa[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
     }
     if (t + 1 == kt_ext) {
-      // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the
-      // forward's LoRA input element (row m, feature n)
-      const float a2 = p.alpha2;
-      const bool drop = p.drop_p > 0.f;
-      const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+      // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the forward's LoRA input
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int m = row0 + wm * 64 + j * 16 + frow;
-          const int n = n0 + wn * 64 + i * 16 + fq * 4;
-          // n is a multiple of 4 and N % 4 == 0 is required with dropout: the 4 registers share one hash group
-          const uint64_t hsh = drop ? vm_hash4(p.drop_seed, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2) : 0ull;
-          const unsigned thr = vm_drop_threshold(p.drop_p);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float s = a2;
-            if (drop) s = vm_keep_bits(hsh, r, thr) ? a2 * inv_keep : 0.f;
-            acc[i][j][r] *= s;
-          }
-        }
+        for (int j = 0; j < 4; ++j)
+          gemm_ext_scale4(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next tile landed and everyone is done reading `buf`
@@ -239,51 +172,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   for (int j = 0; j < 4; ++j) {
     const int ml = wm * 64 + j * 16 + frow;
     if (ml >= nrows) continue;
-    const int64_t m = row0 + ml;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = wn * 64 + i * 16 + fq * 4;
       if (nl >= ncols) continue;
-      const int n = n0 + nl;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      const bool full = nl + 3 < ncols;
-      if (OUT_F32) {
-        const float* bp = (const float*)bias;
-        const float* rp = (const float*)p.residual;
-        float* cp = (float*)p.C + m * p.ldc + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (!full && nl + r >= ncols) break;
-          float x = v[r];
-          if (bp) x += bp[n + r];
-          if (p.act == VM_ACT_GELU) x = gelu_erf(x);
-          else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
-          if (rp) x += rp[m * p.ldr + n + r];
-          v[r] = x;
-        }
-        if (full) *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
-        else for (int r = 0; r < 4 && nl + r < ncols; ++r) cp[r] = v[r];
-      } else {
-        const unsigned short* bp = (const unsigned short*)bias;
-        const unsigned short* rp = (const unsigned short*)p.residual;
-        unsigned short* cp = (unsigned short*)p.C + m * p.ldc + n;
-        unsigned short o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (!full && nl + r >= ncols) { o[r] = 0; continue; }
-          float x = v[r];
-          if (bp) x += bf2f(bp[n + r]);
-          // torch rounds the linear's output to bf16 before the activation and before the residual add
-          if (p.act == VM_ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
-          else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
-          if (rp) x = bf2f(f2bf(x)) + bf2f(rp[m * p.ldr + n + r]);
-          o[r] = f2bf(x);
-        }
-        if (full) *reinterpret_cast<u16x4_t*>(cp) = (u16x4_t){o[0], o[1], o[2], o[3]};
-        else for (int r = 0; r < 4 && nl + r < ncols; ++r) cp[r] = o[r];
-      }
+      gemm_store4<OUT_F32>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
     }
   }
 }
@@ -365,6 +258,24 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
   return VM_OK;
 }
 
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, void* stream);
+
+// 256x256 tiles when they fill the 256 CUs well (>= 80 % of the last round), 128x128 tiles otherwise.
+// VM_GEMM_TILE=128|256 forces a choice (tests / A-B measurements).
+static bool use_tile256(int M, int N, int K, bool segmented) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("VM_GEMM_TILE");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 128) return false;
+  if (forced == 256) return true;
+  if (K < 128) return false;
+  const int t = ((M + 255) / 256 + (segmented ? 1 : 0)) * ((N + 255) / 256);
+  const int rounds = (t + 255) / 256;
+  return (float)t / (float)(rounds * 256) >= 0.80f;
+}
+
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bke = 128 / esz, al = 16 / esz;
   if (!a || !a->A || !a->B || !a->C) return VM_ERR_BAD_ARG;
@@ -403,7 +314,10 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
-  if (esz == 4)
+  if (esz == 2 && use_tile256(a->M, a->N, a->K + a->K2, segmented)) {
+    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, stream);
+    if (rc != VM_OK) return rc;
+  } else if (esz == 4)
     hipLaunchKernelGGL((gemm_nt_k<4, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else if (a->out_dtype == VM_F32)
     hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);

@@ -1,0 +1,199 @@
+// 256x256x64 bf16 NT GEMM for gfx950 — the large-shape variant of gemm_nt_k (same arguments / epilogue).
+//
+// Structure (after the guide's "256² 8-phase" principles, own schedule):
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of C = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16
+//     (128 accumulator VGPRs); one workgroup per CU, 128 KiB of LDS = 2 stages x 4 half-tiles x 16 KiB.
+//   * a K-tile is consumed in 4 phases, one C-quadrant (64 x 32 per wave, 16 MFMAs) each; the operand tiles are cut
+//     into HALF-TILES along the *wave-local* halves (A-h0 = the first 64 rows of every wave row, B-h1 = the second 32
+//     columns of every wave column, ...) so that phase 1 needs {A-h0, B-h0}, phase 2 {B-h1}, phase 3 {A-h1}, phase 4
+//     nothing new. Each phase issues the LDS-DMA (buffer_load ... lds, 2 x 16 B per lane) of ONE half-tile of the
+//     NEXT K-tile, in the order A-h0', B-h0', B-h1', A-h1': every half-tile is issued >= 3 phases before its first
+//     read and overwrites LDS that was last read >= 4 phases earlier.
+//   * loads stay in flight ACROSS the raw s_barrier of every phase: the only waits are counted s_waitcnt vmcnt(4)
+//     (two half-tiles may remain outstanding), never vmcnt(0) inside the steady-state loop.
+#include "vm_common.hpp"
+#include "gemm_common.hpp"
+
+namespace {
+
+constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
+constexpr int STAGE_BYTES2 = 4 * HALF_BYTES;
+constexpr int LDS_BYTES2 = 2 * STAGE_BYTES2;
+
+// LDS-DMA of one half-tile: 16 wave-instructions of 1 KiB (8 rows), 2 per wave. KIND 0: activation (A-h{half}),
+// row r -> tile row (r>>6)*128 + half*64 + (r&63); KIND 1: weight (B-h{half}), r -> (r>>5)*64 + half*32 + (r&31).
+template <int KIND>
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_bytes, int koff, int half, char* lds_half,
+                                           int wave, int lane) {
+  const int r8 = lane >> 3, slot = lane & 7;
+  const int chunk = slot ^ r8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = wave * 2 + i;
+    const int r = inst * 8 + r8;
+    const int trow = KIND == 0 ? ((r >> 6) * 128 + half * 64 + (r & 63)) : ((r >> 5) * 64 + half * 32 + (r & 31));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_half + inst * 1024), 16, trow * ld_bytes + chunk * 16, koff, 0, 0);
+  }
+}
+
+#define VM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tm, tn;
+  gemm_tile_id(p, tm, tn);
+  int row0, nrows, seg;
+  gemm_tile_rows<256>(p, tm, row0, nrows, seg);
+  if (nrows <= 0) return;
+  const int n0 = tn * 256;
+  const int ncols = min(256, p.N - n0);
+  const char* Bw = seg ? p.B1 : p.B0;
+  const char* B2w = seg ? p.B2_1 : p.B2_0;
+
+  const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, nrows * lda_b);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, ncols * ldb_b);
+  const int kt_ext = p.K2 / 64, kt_main = p.K / 64, kt_total = kt_ext + kt_main;
+  __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
+  int lda2_b = 0, ldb2_b = 0;
+  if (kt_ext > 0) {
+    lda2_b = (int)p.lda2 * 2; ldb2_b = (int)p.ldb2 * 2;
+    rA2 = make_rsrc(p.A2, (int64_t)row0 * lda2_b, nrows * lda2_b);
+    rB2 = make_rsrc(B2w, (int64_t)n0 * ldb2_b, ncols * ldb2_b);
+  }
+
+  // half-tile h of K-tile t into stage (t & 1): h = 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1
+  auto stage = [&](int t, int h) {
+    char* dst = smem + (t & 1) * STAGE_BYTES2 + h * HALF_BYTES;
+    const bool ext = t < kt_ext;
+    const int koff = (ext ? t : t - kt_ext) * 128;
+    if (h < 2) stage_half<0>(ext ? rA2 : rA, ext ? lda2_b : lda_b, koff, h, dst, wave, lane);
+    else stage_half<1>(ext ? rB2 : rB, ext ? ldb2_b : ldb_b, koff, h - 2, dst, wave, lane);
+  };
+
+  f32x4_t acc[8][4];   // [m-tile of the wave's 128 rows][n-tile of its 64 columns]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t aF[4][2];       // activation fragments of the current m-half: [m-tile][k-substep]
+  bf16x8_t bF[2][2][2];    // weight fragments: [n-half][n-tile][k-substep]
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int slot0 = fq ^ (frow & 7);
+  const int off_k0 = frow * 128 + slot0 * 16;
+  const int off_k1 = frow * 128 + (slot0 ^ 4) * 16;
+
+  auto read_a = [&](const char* st, int mh) {   // wave's rows of A-h{mh}: wm*64 + i*16 + frow
+    const char* base = st + mh * HALF_BYTES + (wm * 64) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      aF[i][0] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048 + off_k0);
+      aF[i][1] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048 + off_k1);
+    }
+  };
+  auto read_b = [&](const char* st, int nh) {   // wave's rows of B-h{nh}: wn*32 + j*16 + frow
+    const char* base = st + (2 + nh) * HALF_BYTES + (wn * 32) * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bF[nh][j][0] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k0);
+      bF[nh][j][1] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k1);
+    }
+  };
+  auto mma = [&](int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[nh][j][ks], aF[i][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: K-tile 0 completely
+  stage(0, 0); stage(0, 2); stage(0, 3); stage(0, 1);
+  VM_WAIT_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < kt_total; ++t) {
+    const char* st = smem + (t & 1) * STAGE_BYTES2;
+    const bool has_next = t + 1 < kt_total;
+    // ---- phase 1: quadrant (0,0); needs A-h0, B-h0; issues A-h0'
+    read_a(st, 0); read_b(st, 0);
+    if (has_next) stage(t + 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(2);      // B-h1 of this tile has landed
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (0,1); needs B-h1; issues B-h0'
+    read_b(st, 1);
+    if (has_next) stage(t + 1, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(0);      // A-h1 of this tile has landed
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (1,1); needs A-h1; issues B-h1'
+    read_a(st, 1);
+    if (has_next) stage(t + 1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: quadrant (1,0); B-h0 fragments are still in registers; issues A-h1'
+    if (has_next) stage(t + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 == kt_ext) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          gemm_ext_scale4(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+    }
+    if (has_next) VM_WAIT_VMCNT(4);                              // A-h0', B-h0' of the next tile have landed
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const void* bias = seg ? p.bias1 : p.bias0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = wm * 128 + i * 16 + frow;
+    if (ml >= nrows) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nl = wn * 64 + j * 16 + fq * 4;
+      if (nl >= ncols) continue;
+      gemm_store4<OUT_F32>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+    }
+  }
+}
+
+}  // namespace
+
+// called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, void* stream) {
+  GemmParams p = *(const GemmParams*)params;
+  p.tiles_m = (p.M + 255) / 256 + (segmented ? 1 : 0);
+  p.tiles_n = (p.N + 255) / 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm256_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int grid = p.tiles_m * p.tiles_n;
+  if (out_f32) hipLaunchKernelGGL(gemm256_k<true>, dim3(grid), dim3(512), LDS_BYTES2, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm256_k<false>, dim3(grid), dim3(512), LDS_BYTES2, (hipStream_t)stream, p);
+  return VM_OK;
+}

@@ -1,0 +1,124 @@
+// Shared pieces of the NT GEMM kernels (128x128 tile in gemm.hip, 256x256 tile in gemm256.hip).
+#pragma once
+#include "vm_common.hpp"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int GROUP_M = 8;
+
+struct GemmParams {
+  const char* A; int64_t lda;          // leading dimensions in ELEMENTS
+  const char* B0; const char* B1; int64_t ldb;
+  const char* A2; int64_t lda2;
+  const char* B2_0; const char* B2_1; int64_t ldb2;
+  int K2; float alpha2;
+  const void* bias0; const void* bias1;
+  const void* residual; int64_t ldr;
+  void* C; int64_t ldc;
+  int M, N, K;
+  const int32_t* counts_dev;
+  int split;
+  int act;
+  float drop_p; uint64_t drop_seed;
+  int tiles_m, tiles_n;
+};
+
+// Buffer resource from provably wave-uniform words (avoids hipcc's waterfall loops, guide T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, int64_t byte_off, int bytes) {
+  const uint64_t a = (uint64_t)(base + byte_off);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane(bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+
+// XCD-aware bijective tile remap (blocks b and b+8 share an XCD/L2: give each XCD a contiguous chunk of tiles), then
+// GROUP_M-grouped ordering so that concurrently running tiles share A/B panels.
+__device__ __forceinline__ void gemm_tile_id(const GemmParams& p, int& tm, int& tn) {
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int per_group = GROUP_M * p.tiles_n;
+  const int g = bid / per_group;
+  const int gm0 = g * GROUP_M;
+  const int gsz = min(GROUP_M, p.tiles_m - gm0);
+  tm = gm0 + (bid % per_group) % gsz;
+  tn = (bid % per_group) / gsz;
+}
+
+// rows of m-tile `tm` (device-side counts for the token-routed 2-segment form)
+template <int BM_>
+__device__ __forceinline__ void gemm_tile_rows(const GemmParams& p, int tm, int& row0, int& nrows, int& seg) {
+  int M = p.M, split = p.split;
+  if (p.counts_dev) {
+    split = __builtin_amdgcn_readfirstlane(p.counts_dev[0]);
+    M = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
+  }
+  seg = 0;
+  if (split < 0) {
+    row0 = tm * BM_; nrows = min(BM_, M - row0);
+  } else {
+    split = min(split, M);
+    const int t0 = (split + BM_ - 1) / BM_;
+    if (tm < t0) { row0 = tm * BM_; nrows = min(BM_, split - row0); }
+    else { seg = 1; row0 = split + (tm - t0) * BM_; nrows = min(BM_, M - row0); }
+  }
+}
+
+// LoRA-extension post-scale of a lane's 4 consecutive-n accumulator registers (+ dgrad dropout mask)
+__device__ __forceinline__ void gemm_ext_scale4(const GemmParams& p, int64_t m, int n, f32x4_t& a) {
+  const float a2 = p.alpha2;
+  const bool drop = p.drop_p > 0.f;
+  if (!drop) { a *= a2; return; }
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint64_t hsh = vm_hash4(p.drop_seed, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
+  const unsigned thr = vm_drop_threshold(p.drop_p);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r] *= vm_keep_bits(hsh, r, thr) ? a2 * inv_keep : 0.f;
+}
+
+// epilogue of one lane-owned group C[m][n .. n+3]: bias, activation, residual with torch's bf16 rounding points
+template <bool OUT_F32>
+__device__ __forceinline__ void gemm_store4(const GemmParams& p, const void* bias, int64_t m, int n, int ncols_left,
+                                            const f32x4_t& acc) {
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  const bool full = ncols_left >= 4;
+  if (OUT_F32) {
+    const float* bp = (const float*)bias;
+    const float* rp = (const float*)p.residual;
+    float* cp = (float*)p.C + m * p.ldc + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!full && r >= ncols_left) break;
+      float x = v[r];
+      if (bp) x += bp[n + r];
+      if (p.act == VM_ACT_GELU) x = gelu_erf(x);
+      else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
+      if (rp) x += rp[m * p.ldr + n + r];
+      v[r] = x;
+    }
+    if (full) *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+    else for (int r = 0; r < 4 && r < ncols_left; ++r) cp[r] = v[r];
+  } else {
+    const unsigned short* bp = (const unsigned short*)bias;
+    const unsigned short* rp = (const unsigned short*)p.residual;
+    unsigned short* cp = (unsigned short*)p.C + m * p.ldc + n;
+    unsigned short o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!full && r >= ncols_left) { o[r] = 0; continue; }
+      float x = v[r];
+      if (bp) x += bf2f(bp[n + r]);
+      // torch rounds the linear's output to bf16 before the activation and before the residual add
+      if (p.act == VM_ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+      else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
+      if (rp) x = bf2f(f2bf(x)) + bf2f(rp[m * p.ldr + n + r]);
+      o[r] = f2bf(x);
+    }
+    if (full) *reinterpret_cast<u16x4_t*>(cp) = (u16x4_t){o[0], o[1], o[2], o[3]};
+    else for (int r = 0; r < 4 && r < ncols_left; ++r) cp[r] = o[r];
+  }
+}
