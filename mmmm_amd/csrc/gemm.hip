@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 
   // ---- buffer resources (wave-uniform): OOB rows read as zero
   const int lda_b = (int)p.lda * ESZ, ldb_b = (int)p.ldb * ESZ;
-  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, nrows * lda_b);
-  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, ncols * ldb_b);
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
 
   const int kt_ext = p.K2 / BKE;
   const int kt_main = p.K / BKE;
@@ -168,16 +168,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 
   // ---- epilogue
   const void* bias = seg ? p.bias1 : p.bias0;
+  if (OUT_F32) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ml = wm * 64 + j * 16 + frow;
-    if (ml >= nrows) continue;
+    for (int j = 0; j < 4; ++j) {
+      const int ml = wm * 64 + j * 16 + frow;
+      if (ml >= nrows) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int nl = wn * 64 + i * 16 + fq * 4;
-      if (nl >= ncols) continue;
-      gemm_store4<OUT_F32>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+      for (int i = 0; i < 4; ++i) {
+        const int nl = wn * 64 + i * 16 + fq * 4;
+        if (nl >= ncols) continue;
+        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+      }
     }
+  } else {
+    // all waves are past the last K-step barrier: the staging LDS is free. 64 x 64 slab per wave.
+    typedef EpiSlab<64, 64> Slab;
+    char* slab = smem + wave * Slab::BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nl = wn * 64 + i * 16 + fq * 4;
+        epi_put4(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
+      }
+    // same-wave LDS round trip: the compiler orders the ds_reads behind the ds_writes (lgkmcnt)
+    epi_flush<64, 64>(slab, p, row0 + wm * 64, n0 + wn * 64, nrows - wm * 64, ncols - wn * 64, lane);
   }
 }
 
@@ -309,6 +324,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
   p.tiles_m = (a->M + BM - 1) / BM + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   const int grid = p.tiles_m * p.tiles_n;
   const int kind = esz == 2 ? VM_PROF_GEMM_BF16 : VM_PROF_GEMM_F32;
 

@@ -9,10 +9,13 @@
 //     nothing new. Each phase issues the LDS-DMA (buffer_load ... lds, 2 x 16 B per lane) of ONE half-tile of the
 //     NEXT K-tile, in the order A-h0', B-h0', B-h1', A-h1': every half-tile is issued >= 3 phases before its first
 //     read and overwrites LDS that was last read >= 4 phases earlier.
-//   * loads stay in flight ACROSS the raw s_barrier of every phase: the only waits are counted s_waitcnt vmcnt(4)
+//   * loads stay in flight ACROSS the raw s_barriers: the only waits are counted s_waitcnt vmcnt(4)
 //     (two half-tiles may remain outstanding), never vmcnt(0) inside the steady-state loop.
+//   * the two waves of a SIMD (wave rows wm = 0 / 1) are staggered by one barrier interval so that one is in its
+//     MFMA segment while the other is in its LDS-read / DMA-issue segment.
 #include "vm_common.hpp"
 #include "gemm_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   const char* B2w = seg ? p.B2_1 : p.B2_0;
 
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, nrows * lda_b);
-  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, ncols * ldb_b);
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
   const int kt_ext = p.K2 / 64, kt_main = p.K / 64, kt_total = kt_ext + kt_main;
   __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
   int lda2_b = 0, ldb2_b = 0;
@@ -118,63 +121,101 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // Wave rows are STAGGERED by one barrier interval: the two waves that share a SIMD (wave w and w+4, i.e. wm = 0
+  // and wm = 1) alternate between the LDS/DMA segment R_p and the MFMA segment M_p of a phase, so the matrix pipe of
+  // every SIMD always has one wave feeding it (guide "Two waves per SIMD", item 9 / 8-phase template `if (wr==1)`).
+  // Timeline in barrier intervals: row 0 runs R_p in interval 2p and M_p in 2p+1; row 1 runs R_p in 2p+1, M_p in 2p+2.
+  // A half-tile issued in phase p is first read by row 0 in interval 2(p+3); every wave must have retired its part one
+  // barrier earlier, i.e. by the end of interval 2p+5 = end of R_{p+2} for row 1. The same counted wait at the end of
+  // EVERY wave's R segment is sufficient for both rows (row 0 merely retires one interval early) and keeps the steady
+  // state free of wave-dependent branches. The loop is peeled (HN = "a next K-tile exists") so it has no data-dependent
+  // branches between MFMA clusters either.
+  auto ktile = [&](int t, auto hn_tag) {
+    constexpr bool HN = decltype(hn_tag)::value;
+    const char* st = smem + (t & 1) * STAGE_BYTES2;
+    // ---- phase 1: quadrant (0,0); needs A-h0, B-h0; issues A-h0'; retires B-h1 of this tile
+    read_a(st, 0); read_b(st, 0);
+    if (HN) stage(t + 1, 0);
+    if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: quadrant (0,1); needs B-h1; issues B-h0'; retires A-h1 of this tile
+    read_b(st, 1);
+    if (HN) stage(t + 1, 2);
+    if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (1,1); needs A-h1; issues B-h1'
+    read_a(st, 1);
+    if (HN) stage(t + 1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: quadrant (1,0); B-h0 fragments are still in registers; issues A-h1'; retires A-h0', B-h0'
+    if (HN) { stage(t + 1, 1); VM_WAIT_VMCNT(4); }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    mma(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto ext_scale = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        gemm_ext_scale4(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+  };
+
   // prologue: K-tile 0 completely
   stage(0, 0); stage(0, 2); stage(0, 3); stage(0, 1);
   VM_WAIT_VMCNT(0);
   __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
 
-  for (int t = 0; t < kt_total; ++t) {
-    const char* st = smem + (t & 1) * STAGE_BYTES2;
-    const bool has_next = t + 1 < kt_total;
-    // ---- phase 1: quadrant (0,0); needs A-h0, B-h0; issues A-h0'
-    read_a(st, 0); read_b(st, 0);
-    if (has_next) stage(t + 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(2);      // B-h1 of this tile has landed
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 2: quadrant (0,1); needs B-h1; issues B-h0'
-    read_b(st, 1);
-    if (has_next) stage(t + 1, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(0);      // A-h1 of this tile has landed
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3: quadrant (1,1); needs A-h1; issues B-h1'
-    read_a(st, 1);
-    if (has_next) stage(t + 1, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 4: quadrant (1,0); B-h0 fragments are still in registers; issues A-h1'
-    if (has_next) stage(t + 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 == kt_ext) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          gemm_ext_scale4(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
-    }
-    if (has_next) VM_WAIT_VMCNT(4);                              // A-h0', B-h0' of the next tile have landed
-    __builtin_amdgcn_s_barrier();
+  for (int t = 0; t + 1 < kt_total; ++t) {
+    ktile(t, std::true_type{});
+    if (t + 1 == kt_ext) ext_scale();
   }
+  ktile(kt_total - 1, std::false_type{});
+  if (kt_total == kt_ext) ext_scale();
+  if (wm == 0) __builtin_amdgcn_s_barrier();
 
   const void* bias = seg ? p.bias1 : p.bias0;
+  if (OUT_F32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ml = wm * 128 + i * 16 + frow;
-    if (ml >= nrows) continue;
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wm * 128 + i * 16 + frow;
+      if (ml >= nrows) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nl = wn * 64 + j * 16 + fq * 4;
-      if (nl >= ncols) continue;
-      gemm_store4<OUT_F32>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+      for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + fq * 4;
+        if (nl >= ncols) continue;
+        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+      }
+    }
+  } else {
+    // every wave has passed the final barrier: LDS is free. 64 x 64 slab per wave, two passes (upper / lower 64 rows).
+    typedef EpiSlab<64, 64> Slab;
+    char* slab = smem + wave * Slab::BYTES;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = wn * 64 + j * 16 + fq * 4;
+          epi_put4(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
+        }
+      epi_flush<64, 64>(slab, p, row0 + wm * 128 + half * 64, n0 + wn * 64, nrows - wm * 128 - half * 64, ncols - wn * 64, lane);
     }
   }
 }

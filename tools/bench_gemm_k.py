@@ -1,0 +1,15 @@
+import sys, os
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from mmmm_amd import kernels as K
+from tools.bench_kernels import timeit
+dev = torch.device('cuda:0')
+tag = f"tile={os.environ.get('VM_GEMM_TILE','auto')} dbg={os.environ.get('VM_GEMM_DEBUG','0')}"
+M, N = 3648, 12288
+for Kd in (64, 128, 1024, 2048, 4096, 8192):
+    a = torch.randn(M, Kd, device=dev).bfloat16()
+    w = (torch.randn(N, Kd, device=dev) / 64).bfloat16()
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: K.gemm(a, w, out=out), iters=30)
+    print(tag, f'K={Kd}', f'{ms*1e3:.0f} us', flush=True)
