@@ -15,6 +15,7 @@
 #include <vector>
 #include <mutex>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -76,19 +77,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     rB2 = make_rsrc(B2w, (int64_t)n0 * ldb2_b, ncols * ldb2_b);
   }
 
-  auto stage = [&](int t, int buf) {
-    char* sa = smem + buf * STAGE_BYTES;       // activation tile (MFMA B operand)
-    char* sb = sa + TILE_BYTES;                // weight tile (MFMA A operand)
-    if (t < kt_ext) {
-      stage_tile(rA2, lda2_b, t * 128, sa, wave, lane);
-      stage_tile(rB2, ldb2_b, t * 128, sb, wave, lane);
-    } else {
-      const int koff = (t - kt_ext) * 128;
-      stage_tile(rA, lda_b, koff, sa, wave, lane);
-      stage_tile(rB, ldb_b, koff, sb, wave, lane);
-    }
-  };
-
   f32x4_t acc[4][4];  // [n-subtile i][m-subtile j]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -110,13 +98,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     off_k1 = frow * 128 + ((2 * fq + 1) ^ (frow & 7)) * 16;
   }
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // tile 0 landed
-
-  for (int t = 0; t < kt_total; ++t) {
+  // one K-step: issue the LDS-DMA of tile t+1 (HN), MFMA over tile t, wait for the DMA, barrier.
+  // The K loop is peeled on HN / on the extension boundary so the steady state has no data-dependent branches
+  // between the MFMA clusters (scalar branches cost tens of cycles each on this chip).
+  auto kstep = [&](int t, auto hn_tag, auto ext_next_tag) {
+    constexpr bool HN = decltype(hn_tag)::value;
+    constexpr bool EXT_NEXT = decltype(ext_next_tag)::value;      // tile t+1 is an extension tile
     const int buf = t & 1;
-    if (t + 1 < kt_total) stage(t + 1, buf ^ 1);
+    if (HN) {
+      char* sa = smem + (buf ^ 1) * STAGE_BYTES;
+      char* sb = sa + TILE_BYTES;
+      if (EXT_NEXT) {
+        stage_tile(rA2, lda2_b, (t + 1) * 128, sa, wave, lane);
+        stage_tile(rB2, ldb2_b, (t + 1) * 128, sb, wave, lane);
+      } else {
+        const int koff = (t + 1 - kt_ext) * 128;
+        stage_tile(rA, lda_b, koff, sa, wave, lane);
+        stage_tile(rB, ldb_b, koff, sb, wave, lane);
+      }
+    }
     const char* sa = smem + buf * STAGE_BYTES + wm * (64 * 128);
     const char* sb = smem + buf * STAGE_BYTES + TILE_BYTES + wn * (64 * 128);
     if (ESZ == 2) {
@@ -154,19 +154,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s >> 2][s & 3], xa[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 == kt_ext) {
-      // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the forward's LoRA input
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          gemm_ext_scale4(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next tile landed and everyone is done reading `buf`
+  };
+  auto ext_scale = [&]() {
+    // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the forward's LoRA input
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        gemm_ext_scale4(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
+  };
+  const std::true_type T_{};
+  const std::false_type F_{};
+
+  if (kt_ext > 0) {
+    stage_tile(rA2, lda2_b, 0, smem, wave, lane);
+    stage_tile(rB2, ldb2_b, 0, smem + TILE_BYTES, wave, lane);
+  } else {
+    stage_tile(rA, lda_b, 0, smem, wave, lane);
+    stage_tile(rB, ldb_b, 0, smem + TILE_BYTES, wave, lane);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // tile 0 landed
+
+  int t = 0;
+  for (; t + 1 < kt_ext; ++t) kstep(t, T_, T_);               // extension tiles followed by an extension tile
+  if (kt_ext > 0) {                                           // last extension tile
+    if (kt_main > 0) kstep(t, T_, F_); else kstep(t, F_, F_);
+    ext_scale();
+    ++t;
+  }
+  for (; t + 1 < kt_total; ++t) kstep(t, T_, F_);             // steady state
+  if (t < kt_total) kstep(t, F_, F_);                         // last main tile
 
   // ---- epilogue
+  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
 #pragma unroll
@@ -184,12 +207,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     // all waves are past the last K-step barrier: the staging LDS is free. 64 x 64 slab per wave.
     typedef EpiSlab<64, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
+    const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int nl = wn * 64 + i * 16 + fq * 4;
-        epi_put4(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
+        if (plain) epi_put4<0>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
+        else epi_put4<1>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
       }
     // same-wave LDS round trip: the compiler orders the ds_reads behind the ds_writes (lgkmcnt)
     epi_flush<64, 64>(slab, p, row0 + wm * 64, n0 + wn * 64, nrows - wm * 64, ncols - wn * 64, lane);

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   if (kt_total == kt_ext) ext_scale();
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
+  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
 #pragma unroll
@@ -206,15 +207,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     // every wave has passed the final barrier: LDS is free. 64 x 64 slab per wave, two passes (upper / lower 64 rows).
     typedef EpiSlab<64, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
+    const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      if (plain) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int nl = wn * 64 + j * 16 + fq * 4;
-          epi_put4(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
-        }
+          for (int j = 0; j < 4; ++j)
+            epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + fq * 4;
+            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
+          }
+      }
       epi_flush<64, 64>(slab, p, row0 + wm * 128 + half * 64, n0 + wn * 64, nrows - wm * 128 - half * 64, ncols - wn * 64, lane);
     }
   }

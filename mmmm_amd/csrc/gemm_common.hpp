@@ -135,24 +135,32 @@ struct EpiSlab {
   static constexpr int BYTES = ROWS * PITCH;
 };
 
-// write one lane-owned group (row r, cols c..c+3 of the slab) after bias + activation
+// write one lane-owned group (row r, cols c..c+3 of the slab) after bias + activation.
+// MODE 0: no bias, no activation (the common case: no per-element branches at all); MODE 1: generic.
+template <int MODE>
 __device__ __forceinline__ void epi_put4(char* slab, int pitch, int r, int c, const GemmParams& p, const void* bias, int n,
                                          int ncols_left, const f32x4_t& acc) {
-  const unsigned short* bp = (const unsigned short*)bias;
   u16x4_t o;
+  if (MODE == 0) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float x = acc[e];
-    if (bp && e < ncols_left) x += bf2f(bp[n + e]);
-    if (p.act == VM_ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
-    else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
-    o[e] = f2bf(x);
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e]);
+  } else {
+    const unsigned short* bp = (const unsigned short*)bias;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = acc[e];
+      if (bp && e < ncols_left) x += bf2f(bp[n + e]);
+      if (p.act == VM_ACT_GELU) x = gelu_erf(bf2f(f2bf(x)));
+      else if (p.act == VM_ACT_RELU) x = fmaxf(x, 0.f);
+      o[e] = f2bf(x);
+    }
   }
   *reinterpret_cast<u16x4_t*>(slab + r * pitch + c * 2) = o;
 }
 
 // flush ROWS x COLS bf16 from the slab to C[m0 + r][n0 + c], one wave, 16 B per lane; rows >= rows_valid and columns
-// >= cols_valid are skipped; the residual (bf16, same layout as C) is added after rounding, as torch does
+// >= cols_valid are skipped; the residual (bf16, same layout as C) is added after rounding, as torch does.
+// Interior tiles with aligned leading dimensions take a path without per-element control flow.
 template <int ROWS, int COLS>
 __device__ __forceinline__ void epi_flush(const char* slab, const GemmParams& p, int64_t m0, int n0, int rows_valid,
                                           int cols_valid, int lane) {
@@ -162,27 +170,39 @@ __device__ __forceinline__ void epi_flush(const char* slab, const GemmParams& p,
   const int ch = lane % CPR, rr = lane / CPR;
   const unsigned short* rp = (const unsigned short*)p.residual;
   const bool vec_ok = (p.ldc % 8 == 0) && (n0 % 8 == 0) && (!rp || p.ldr % 8 == 0);
+  if (p.dbg & 64) return;                       // timing experiment: epilogue without stores
+  if (vec_ok && rows_valid >= ROWS && cols_valid >= COLS) {
+    unsigned short* cbase = (unsigned short*)p.C + (m0 + rr) * p.ldc + n0 + ch * 8;
+    const char* sbase = slab + rr * PITCH + ch * 16;
+    if (!rp) {
 #pragma unroll
+      for (int it = 0; it < ROWS / RPI; ++it)
+        *reinterpret_cast<u16x8_t*>(cbase + (int64_t)it * RPI * p.ldc) = *reinterpret_cast<const u16x8_t*>(sbase + it * RPI * PITCH);
+    } else {
+      const unsigned short* rbase = rp + (m0 + rr) * p.ldr + n0 + ch * 8;
+#pragma unroll
+      for (int it = 0; it < ROWS / RPI; ++it) {
+        u16x8_t v = *reinterpret_cast<const u16x8_t*>(sbase + it * RPI * PITCH);
+        const u16x8_t rv = *reinterpret_cast<const u16x8_t*>(rbase + (int64_t)it * RPI * p.ldr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
+        *reinterpret_cast<u16x8_t*>(cbase + (int64_t)it * RPI * p.ldc) = v;
+      }
+    }
+    return;
+  }
+  // edge tiles / unaligned leading dimensions: element-wise, not performance relevant
   for (int it = 0; it < ROWS / RPI; ++it) {
     const int r = it * RPI + rr;
     if (r >= rows_valid) continue;
     const int c = ch * 8;
-    if (c >= cols_valid) continue;
-    u16x8_t v = *reinterpret_cast<const u16x8_t*>(slab + r * PITCH + c * 2);
     const int64_t m = m0 + r;
-    unsigned short* cp = (unsigned short*)p.C + m * p.ldc + n0 + c;
-    const bool full = c + 8 <= cols_valid;
-    if (rp) {
-      const unsigned short* rrp = rp + m * p.ldr + n0 + c;
-      if (full && vec_ok) {
-        const u16x8_t rv = *reinterpret_cast<const u16x8_t*>(rrp);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
-      } else {
-        for (int e = 0; e < 8 && c + e < cols_valid; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rrp[e]));
-      }
+    const unsigned short* sp = reinterpret_cast<const unsigned short*>(slab + r * PITCH + c * 2);
+    for (int e = 0; e < 8; ++e) {
+      if (c + e >= cols_valid) break;
+      float x = bf2f(sp[e]);
+      if (rp) x = bf2f(f2bf(x + bf2f(rp[m * p.ldr + n0 + c + e])));
+      ((unsigned short*)p.C)[m * p.ldc + n0 + c + e] = f2bf(x);
     }
-    if (full && vec_ok) *reinterpret_cast<u16x8_t*>(cp) = v;
-    else for (int e = 0; e < 8 && c + e < cols_valid; ++e) cp[e] = v[e];
   }
 }
