@@ -35,8 +35,12 @@ struct DownP {
   float drop_p; uint64_t seed;
 };
 
-__global__ __launch_bounds__(256) void lora_down_k(const DownP p) {
-  __shared__ float red[4][16][64 + 1];
+// 8 waves per 16-row slab: wave w takes the 32-wide k-steps w, w+8, w+16, ... (any K % 32 == 0), 4 k-steps of loads in
+// flight per wave; partial sums are reduced through LDS. (4 waves / contiguous K quarters left the chip at ~3.5 waves
+// per CU and latency bound: 57 us per call at M=3648, K=4096.)
+constexpr int DOWN_WAVES = 8;
+__global__ __launch_bounds__(DOWN_WAVES * 64) void lora_down_k(const DownP p) {
+  __shared__ float red[DOWN_WAVES][16][64 + 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int M = p.M, split = p.split;
@@ -59,35 +63,46 @@ __global__ __launch_bounds__(256) void lora_down_k(const DownP p) {
   const bool rvalid = frow < nrows;
   const int64_t m = row0 + frow;
   const unsigned short* xr = p.x + (rvalid ? m : row0) * p.ldx;
-  const int kw = p.K / 4;                         // K slice of this wave (K % 128 == 0)
-  const int kbeg = wave * kw;
   const bool drop = p.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(p.drop_p);
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const int nsteps = p.K / 32;
 
   f32x4_t acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int k0 = kbeg; k0 < kbeg + kw; k0 += 32) {
-    const int kk = k0 + 8 * fq;
+
+  auto load_x = [&](int step) -> u16x8_t {
     u16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (rvalid) xv = *reinterpret_cast<const u16x8_t*>(xr + kk);
-    if (drop) {
-      const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
-      const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
+    if (rvalid && step < nsteps) xv = *reinterpret_cast<const u16x8_t*>(xr + step * 32 + 8 * fq);
+    return xv;
+  };
+  for (int s0 = wave; s0 < nsteps; s0 += DOWN_WAVES * 4) {
+    u16x8_t xv[4];
+    bf16x8_t wa[4][4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bool keep = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr);
-        // same rounding as the standalone dropout kernel: bf16(x * 1/(1-p))
-        xv[e] = keep ? f2bf(bf2f(xv[e]) * inv_keep) : (unsigned short)0;
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int step = s0 + u * DOWN_WAVES;
+      xv[u] = load_x(step);
+      const int kk = min(step, nsteps - 1) * 32 + 8 * fq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wa[u][i] = *reinterpret_cast<const bf16x8_t*>(A + (int64_t)(16 * i + frow) * p.lda + kk);
     }
-    const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8_t wa = *reinterpret_cast<const bf16x8_t*>(A + (int64_t)(16 * i + frow) * p.lda + kk);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[i], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int step = s0 + u * DOWN_WAVES;
+      if (step >= nsteps) break;
+      const int kk = step * 32 + 8 * fq;
+      if (drop) {
+        const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
+        const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)   // same rounding as the standalone dropout kernel: bf16(x * 1/(1-p))
+          xv[u][e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(xv[u][e]) * inv_keep) : (unsigned short)0;
+      }
+      const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv[u]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u][i], xb, acc[i], 0, 0, 0);
     }
   }
   // D[row = r_local][col = m_local]: lane holds r = 16 i + 4 fq + e for m = frow
@@ -96,14 +111,14 @@ __global__ __launch_bounds__(256) void lora_down_k(const DownP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[wave][frow][16 * i + 4 * fq + e] = acc[i][e];
   __syncthreads();
-  // 16 x 64 outputs, 256 threads: 4 consecutive r per thread
-  const int om = tid >> 4, orr = (tid & 15) * 4;
+  // 16 x 64 outputs over 512 threads: 2 consecutive r per thread
+  const int om = tid >> 5, orr = (tid & 31) * 2;
   if (om < nrows) {
-    u16x4_t o;
+    float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = f2bf(red[0][om][orr + e] + red[1][om][orr + e] + red[2][om][orr + e] + red[3][om][orr + e]);
-    *reinterpret_cast<u16x4_t*>(p.t + (int64_t)(row0 + om) * p.ldt + orr) = o;
+    for (int w = 0; w < DOWN_WAVES; ++w) { v0 += red[w][om][orr]; v1 += red[w][om][orr + 1]; }
+    const unsigned packed = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+    *reinterpret_cast<unsigned*>(p.t + (int64_t)(row0 + om) * p.ldt + orr) = packed;
   }
 }
 
@@ -258,7 +273,7 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
                  int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed, void* stream) {
   if (!x || !A0 || !t) return VM_ERR_BAD_ARG;
   if (M <= 0) return VM_OK;
-  if (R != 64 || K % 128 || ldx % 8 || lda % 8 || ldt % 4) return VM_ERR_UNSUPPORTED;
+  if (R != 64 || K % 32 || ldx % 8 || lda % 8 || ldt % 2) return VM_ERR_UNSUPPORTED;
   const bool segmented = counts_dev != nullptr || split >= 0;
   if (segmented && !A1) return VM_ERR_BAD_ARG;
   DownP p;
@@ -272,7 +287,7 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   const int grid = (M + 15) / 16 + (segmented ? 1 : 0);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  hipLaunchKernelGGL(lora_down_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(lora_down_k, dim3(grid), dim3(DOWN_WAVES * 64), 0, (hipStream_t)stream, p);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * M * 64.0 * K);
   VM_LAUNCH_CHECK();
   return VM_OK;

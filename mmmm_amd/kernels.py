@@ -126,7 +126,7 @@ def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None,
 
 
 def lora_down_supported(x: torch.Tensor, A: torch.Tensor) -> bool:
-    return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 128 == 0
+    return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 32 == 0
 
 
 def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = None, segment: int = -1,
@@ -292,8 +292,8 @@ def embedding_bwd(dout, ids: torch.Tensor, rows: torch.Tensor, dweight: torch.Te
 
 def ce_fwd(logits, labels, vocab: int, nrows: torch.Tensor | None = None):
     rows = logits.shape[0]
-    row_loss = torch.zeros(rows, dtype=torch.float32, device=logits.device)
-    lse = torch.zeros(rows, dtype=torch.float32, device=logits.device)
+    row_loss = torch.zeros(rows, dtype=torch.float32, device=logits.device)   # rows >= n_rows must read 0 in the dot product
+    lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
     hip.call('vm_ce_fwd', ptr(logits), _ld(logits), ptr(labels), ptr(row_loss), ptr(lse), rows, vocab, dtype_code(logits.dtype),
              ptr(nrows), stream())
     return row_loss, lse
@@ -361,8 +361,9 @@ def attn_fwd(q, k, v, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, 
     assert q.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
     rows = q.shape[0]
     total_pos_max = rows if total_pos_max is None else total_pos_max
-    out = torch.zeros(rows, n_heads * head_dim, dtype=q.dtype, device=q.device)
-    lse = torch.zeros(n_heads, total_pos_max, dtype=torch.float32, device=q.device)
+    # rows that belong to no sequence (packed-layout padding) are never read downstream; lse likewise
+    out = torch.empty(rows, n_heads * head_dim, dtype=q.dtype, device=q.device)
+    lse = torch.empty(n_heads, total_pos_max, dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max)
     hip.call('vm_attn_fwd_bf16', C.addressof(a), stream())
     return out, lse
@@ -373,7 +374,7 @@ def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim,
     rows = q.shape[0]
     total_pos_max = rows if total_pos_max is None else total_pos_max
     dout = _c(dout)
-    dqkv = torch.zeros(rows, 3, n_heads * head_dim, dtype=q.dtype, device=q.device)
+    dqkv = torch.empty(rows, 3, n_heads * head_dim, dtype=q.dtype, device=q.device)   # every valid row is written by the dq / dkv kernels
     dq, dk, dv = dqkv[:, 0], dqkv[:, 1], dqkv[:, 2]
     delta = torch.empty(n_heads, total_pos_max, dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max)

@@ -67,13 +67,15 @@ class MaskDecoder(nn.Module):
     def forward(self, image_embeddings: torch.Tensor, image_pe: torch.Tensor, sparse_prompt_embeddings: torch.Tensor,
                 dense_prompt_embeddings: torch.Tensor, text_embedding: torch.Tensor, patch_size_z: int, grid: tuple,
                 need_masks: bool = True):
-        """image_embeddings [Ns, C] channel-last tokens of ONE image (grid d,h,w), image_pe [Ns, C],
-        sparse [P, 1, C], dense [1, C] -> masks [P, M, D', H', W'], mask_tokens_out [P, M, C]   (reference :89-149)"""
+        """image_embeddings: channel-last tokens of the image each prompt refers to, already replicated per prompt
+        [P, Ns, C] (the reference's `repeat_interleave`, :110-116) — prompts of several images with the same grid are
+        decoded in ONE pass; image_pe [Ns, C]; sparse [P, 1, C]; dense [1, C]
+        -> masks [P, M, D', H', W'], mask_tokens_out [P, M, C]   (reference :89-149)"""
         P = sparse_prompt_embeddings.shape[0]
         C = self.transformer_dim
         out_tokens = torch.cat([self.iou_token.weight, self.mask_tokens.weight], dim=0)
         tokens = torch.cat([out_tokens[None].expand(P, -1, -1), sparse_prompt_embeddings], dim=1)
-        src = (image_embeddings + dense_prompt_embeddings)[None].expand(P, -1, -1).contiguous()      # image replicated per prompt
+        src = image_embeddings + dense_prompt_embeddings
         pos = image_pe[None].expand(P, -1, -1).contiguous()
         hs, src = self.transformer(src, pos, tokens, tokens)
         mask_tokens_out = hs[:, 1:1 + self.num_mask_tokens]

@@ -38,18 +38,43 @@ class Sam(nn.Module):
     def num_mask_tokens(self):
         return self.mask_decoder.num_mask_tokens
 
-    def _predict_masks(self, text_embedding, image_tokens, grid, patch_size_z, need_masks=True):
-        sparse, dense = self.prompt_encoder(grid, text_embedding=text_embedding)
-        return self.mask_decoder(image_tokens, self.prompt_encoder.get_dense_pe(grid), sparse.to(text_embedding.dtype), dense,
-                                 text_embedding, patch_size_z, grid, need_masks=need_masks)
+    def _decode_groups(self, tokens, grids, patch_size, text_embedding, need_masks=True):
+        """Run the mask decoder once per group of samples that share (grid, patch_size_z) instead of once per sample
+        (reference sam.py:76-80 loops samples): prompts of a group are concatenated along the prompt axis, each
+        prompt attends to its own image's tokens. Returns per-sample (low-res masks | None, mask-token embeddings)."""
+        B = len(tokens)
+        groups: dict[tuple, list[int]] = {}
+        for i in range(B):
+            groups.setdefault((tuple(grids[i]), patch_size[i][0]), []).append(i)
+        lows: list = [None] * B
+        embs: list = [None] * B
+        for (grid, pz), idx in groups.items():
+            counts = [text_embedding[i].shape[0] for i in idx]
+            text = torch.cat([text_embedding[i] for i in idx], dim=0)
+            if text.shape[0] == 0:
+                for i in idx:
+                    c = self.mask_embed_dim
+                    embs[i] = text.new_zeros(0, self.num_mask_tokens, c) + 0 * tokens[i].sum()
+                    lows[i] = text.new_zeros(0, self.num_mask_tokens, *(1,) * 3) if need_masks else None
+                continue
+            src = torch.cat([tokens[i][None].expand(n, -1, -1) for i, n in zip(idx, counts) if n > 0], dim=0)
+            sparse, dense = self.prompt_encoder(grid, text_embedding=text)
+            low, emb = self.mask_decoder(src, self.prompt_encoder.get_dense_pe(grid), sparse.to(text.dtype), dense, text, pz, grid,
+                                         need_masks=need_masks)
+            off = 0
+            for i, n in zip(idx, counts):
+                embs[i] = emb[off:off + n]
+                lows[i] = low[off:off + n] if low is not None else None
+                off += n
+        return lows, embs
 
     def forward(self, image: list[torch.Tensor], patch_size: list[tuple], text_embedding: list[torch.Tensor]):
         """-> per sample [P, D, H, W] semantic mask logits at image resolution (reference :72-87)"""
         tokens, grids = self.image_encoder(image, patch_size)
+        lows, _ = self._decode_groups(tokens, grids, patch_size, text_embedding)
         outs = []
         for i in range(len(image)):
-            low, _ = self._predict_masks(text_embedding[i], tokens[i], grids[i], patch_size[i][0])
-            low = low[:, 0]
+            low = lows[i][:, 0]
             outs.append(F.interpolate(low[None], image[i].shape[1:], mode='trilinear')[0] if low.shape[0] > 0 else low)
         return outs
 
@@ -73,13 +98,12 @@ class InstanceSam(Sam):
         """training_step only consumes boxes / disc_logit (mmmm.py:214-219): the mask branch of the instance decoder
         (frozen by _freeze_sam_unused) is skipped unless need_masks=True."""
         tokens, grids = self.image_encoder(image, patch_size)
-        lows, boxes, discs = [], [], []
-        for i in range(len(image)):
-            low, emb = self._predict_masks(text_embedding[i], tokens[i], grids[i], patch_size[i][0], need_masks=need_masks)
+        lows, embs = self._decode_groups(tokens, grids, patch_size, text_embedding, need_masks=need_masks)
+        boxes, discs = [], []
+        for emb in embs:
             x = self.box_head[4](Fh.relu(self.box_head[2](Fh.relu(self.box_head[0](emb)))))
             boxes.append(x.float().sigmoid())
             discs.append(self.disc_head[2](Fh.relu(self.disc_head[0](emb[:, 1:].contiguous())))[..., 0])
-            lows.append(low)
         masks = [F.interpolate(m, image[i].shape[1:], mode='trilinear') if m is not None else None for i, m in enumerate(lows)]
         return InstanceSamOutput(masks, lows, boxes, discs)
 
