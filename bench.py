@@ -200,6 +200,9 @@ def main():
     ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
     ap.add_argument('--depth-scale', type=float, default=1.0, help='debug only: <1 shrinks depth and invalidates the number')
+    ap.add_argument('--checkpointing', default=os.environ.get('VM_CHECKPOINTING', 'hbm'), choices=['hbm', 'reference'],
+                    help="'reference': recompute every transformer layer in backward (mmmm.py:232-233); 'hbm': keep the "
+                         "activations of as many layers as the free HBM of this device holds (same results, less recompute)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     args = ap.parse_args()
@@ -230,12 +233,29 @@ def main():
         loss = model.training_step(batch)
         loss.backward()
         ddp.finish()
-        torch.nn.utils.clip_grad_norm_(trainable, 1.0, foreach=True)
+        ddp.clip_grad_norm_(1.0)                      # gradient_clip_val 1 (conf/phase-vg/fit.yaml), on the flat buckets
         opt.step()
         return loss
 
+    from mmmm_amd.models.lora import ActivationBudget
+    plan = 'every layer recomputed'
+    if args.checkpointing == 'hbm':
+        # planning step (untimed, not a warmup step): peak HBM with every layer checkpointed -> what is left over
+        # becomes the activation budget of the following steps
+        torch.cuda.reset_peak_memory_stats()
+        step()
+        torch.cuda.synchronize()
+        total_hbm = torch.cuda.get_device_properties(device).total_memory
+        budget = int(0.88 * total_hbm) - torch.cuda.max_memory_allocated() - (8 << 30)
+        if world > 1:
+            t = torch.tensor([budget], device=device, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            budget = int(t.item())
+        ActivationBudget.limit = max(budget, 0)
     for _ in range(args.warmup):
         loss = step()
+    if args.checkpointing == 'hbm':
+        plan = 'hbm budget %.0f GB: kept/total layers %s' % (ActivationBudget.limit / 2**30, ActivationBudget.last_plan)
     use_events = not args.no_kernel_events
     if use_events:
         K.prof_reset()
@@ -268,7 +288,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05',
-                       'gradient_checkpointing': True, 'optimizer': 'AdamW(fused) + clip 1.0', 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'optimizer': 'AdamW(fused) + clip 1.0', 'depth_scale': args.depth_scale},
             'loss': loss_v,
             'model_tflops_per_image': fl_sample / 1e12,
             'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,

@@ -225,6 +225,12 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 
+/* A table of independent small transposes in ONE launch: desc_dev holds n records of six int64
+ * {src ptr, dst ptr, rows, cols, ld_src, ld_dst}; dst[c, r] = src[r, c]. Used to refresh the K-contiguous copies of
+ * every LoRA factor (peft lora_A/lora_B of scripts/cli.py:82-85) once per optimizer step instead of once per use.
+ * tiles_per_entry = grid.x (entries with more 64x64 tiles loop). n <= 65535. */
+int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, int dtype, void* stream);
+
 /* same, restricted to one row segment of the token-routed layout:
  * segment 0 = rows [0, counts[0]), segment 1 = rows [counts[0], counts[1]) (device counts);
  * out[c, i] = in[begin + i, c], zero beyond the segment. Feeds the per-expert LoRA weight gradients. */

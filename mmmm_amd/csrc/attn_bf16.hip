@@ -210,18 +210,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_k(const AttnP p) {
 // ----------------------------------------------------------------------------- delta = rowsum(dO * O)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_k(const AttnP p, int n_seq) {
-  // one wave per (position, head)
+  // one wave per position; a lane owns one 8-element chunk (16-byte loads) and a pass covers as many WHOLE heads as fit
+  // in 64 lanes, so the per-head sum is a gather over HD/8 neighbouring lanes
+  constexpr int CPH = HD / 8;                       // chunks per head
+  constexpr int HPP = 64 / CPH;                     // heads per pass
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gpos = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int total = p.cu[n_seq];
-  const int gpos = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
   if (gpos >= total) return;
   const int64_t r = phys_row(p, gpos);
-  float acc = 0.f;
-  for (int d = lane; d < HD; d += 64)
-    acc += bf2f(p.dout[r * p.lddo + head * HD + d]) * bf2f(p.out[r * p.ldo + head * HD + d]);
-  acc = wave_sum(acc);
-  if (lane == 0) p.delta[(int64_t)head * p.total_pos_max + gpos] = acc;
+  const unsigned short* dop = p.dout + r * p.lddo;
+  const unsigned short* op = p.out + r * p.ldo;
+  const int hl = lane / CPH;                        // head within the pass (lanes >= HPP*CPH idle)
+  const int first = hl * CPH;
+  for (int h0 = 0; h0 < p.n_heads; h0 += HPP) {
+    const int head = h0 + hl;
+    const bool live = hl < HPP && head < p.n_heads;
+    float acc = 0.f;
+    if (live) {
+      const int off = head * HD + (lane - first) * 8;
+      const u16x8_t a = *reinterpret_cast<const u16x8_t*>(dop + off);
+      const u16x8_t b = *reinterpret_cast<const u16x8_t*>(op + off);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(b[e]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPH; ++j) sum += __shfl(acc, (first + j) & 63, 64);
+    if (live && lane == first) p.delta[(int64_t)head * p.total_pos_max + gpos] = sum;
+  }
 }
 
 // ----------------------------------------------------------------------------- backward: dQ (query-stationary)
@@ -500,9 +517,9 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
 
 int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   if (!args_ok(a) || !a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return VM_ERR_BAD_ARG;
-  if (a->lddo % 8 || a->lddq % 4 || a->lddk % 4 || a->lddv % 4) return VM_ERR_BAD_ARG;
+  if (a->lddo % 8 || a->ldo % 8 || a->lddq % 4 || a->lddk % 4 || a->lddv % 4) return VM_ERR_BAD_ARG;
   AttnP p = to_params(a);
-  const int64_t items = (int64_t)a->total_pos_max * a->n_heads;
+  const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);

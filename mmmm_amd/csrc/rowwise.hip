@@ -413,6 +413,35 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
   }
 }
 
+// one launch for a whole table of small transposes (every LoRA factor of the model after an optimizer step):
+// desc[i] = {src, dst, rows, cols, ld_src, ld_dst} as int64; blockIdx.y = table entry, blockIdx.x = 64x64 tile
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_batched_k(const int64_t* __restrict__ desc) {
+  __shared__ T tile[64][64 + 2];
+  const int64_t* d = desc + (int64_t)blockIdx.y * 6;
+  const T* in = reinterpret_cast<const T*>(d[0]);
+  T* out = reinterpret_cast<T*>(d[1]);
+  const int rows = (int)d[2], cols = (int)d[3];
+  const int64_t ld_in = d[4], ld_out = d[5];
+  const int tiles_c = (cols + 63) / 64, tiles_r = (rows + 63) / 64;
+  for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      T v = Elem<T>::st(0.f);
+      if (r < rows && c < cols) v = in[(int64_t)r * ld_in + c];
+      tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- column sums (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
@@ -709,6 +738,15 @@ int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int r
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                            ld_in, (T*)out, ld_out, rows, cols, nrows_dev, (const int32_t*)nullptr, 0));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, int dtype, void* stream) {
+  if (n <= 0) return VM_OK;
+  if (!desc_dev || tiles_per_entry <= 0 || n > 65535) return VM_ERR_BAD_ARG;
+  dim3 grid(tiles_per_entry, n);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_batched_k<T>, grid, dim3(256), 0, (hipStream_t)stream, desc_dev));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

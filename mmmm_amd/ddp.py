@@ -126,6 +126,20 @@ class BucketedGradAllReduce:
                     off += (p.numel() + 7) // 8 * 8
         self._next = 0
 
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ (L2) evaluated on the flat bucket buffers: a few reductions and one scale
+        per bucket instead of one tiny kernel per parameter (the 8-byte alignment padding between slots is zero)."""
+        sq = None
+        for b in self.buckets:
+            v = torch.linalg.vector_norm(b.buffer, 2, dtype=torch.float32)
+            sq = v * v if sq is None else sq + v * v
+        total = sq.sqrt()
+        coef = torch.clamp(max_norm / (total + eps), max=1.0)
+        for b in self.buckets:
+            b.buffer.mul_(coef.to(b.buffer.dtype))
+        return total
+
     def remove(self):
         for h in self._hooks:
             h.remove()

@@ -26,6 +26,11 @@ class LinearMeta:
     drop_seed: int = 0
     act: int = hip.ACT_NONE      # fused epilogue activation (only when the input needs no pre-activation later)
     out_dtype: torch.dtype | None = None
+    # resident K-contiguous copies of the LoRA factors (models/lora.py LoraTransposes); None -> transposed per use
+    At0: torch.Tensor | None = None
+    Bt0: torch.Tensor | None = None
+    At1: torch.Tensor | None = None
+    Bt1: torch.Tensor | None = None
 
 
 def _t(w: torch.Tensor) -> torch.Tensor:
@@ -98,12 +103,16 @@ class _Linear(Function):
         g = [None] * 14
         u = None
         if lora and (need[1] or need[7] or need[12]):
-            u = _lora_project(dy, _t(B0), _t(B1) if gated else None, gated, counts)       # [M, r] = dy · B
+            Bt0 = meta.Bt0 if meta.Bt0 is not None else _t(B0)
+            Bt1 = (meta.Bt1 if meta.Bt1 is not None else _t(B1)) if gated else None
+            u = _lora_project(dy, Bt0, Bt1, gated, counts)                                # [M, r] = dy · B
         if need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None
             dyp, wt0, wt1 = _padk(dy, wt0, wt1)
-            g[1] = K.gemm(dyp, wt0, w1=wt1, a2=u, b2=_t(A0) if lora else None, b2_1=_t(A1) if (lora and gated) else None,
+            At0 = (meta.At0 if meta.At0 is not None else _t(A0)) if lora else None
+            At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
+            g[1] = K.gemm(dyp, wt0, w1=wt1, a2=u, b2=At0, b2_1=At1,
                           alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
         if ctx.has_residual and need[2]:
             g[2] = dy

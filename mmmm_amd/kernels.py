@@ -97,6 +97,12 @@ def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = 
     return out
 
 
+def transpose_batched(desc: torch.Tensor, n: int, tiles_per_entry: int, dtype: torch.dtype):
+    """desc: int64 [n, 6] on the device — {src, dst, rows, cols, ld_src, ld_dst}; one launch for the whole table"""
+    assert desc.dtype == torch.int64 and desc.is_contiguous() and desc.numel() >= n * 6
+    hip.call('vm_transpose_batched', ptr(desc), n, tiles_per_entry, dtype_code(dtype), stream())
+
+
 def transpose_segment(x: torch.Tensor, counts: torch.Tensor, segment: int, pad_to: int = 64) -> torch.Tensor:
     """transpose of row segment `segment` (0: [0,counts[0]), 1: [counts[0],counts[1])) -> [cols, rows_padded]"""
     rows, cols = x.shape

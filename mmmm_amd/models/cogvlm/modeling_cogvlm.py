@@ -23,7 +23,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ... import functional as Fh
 from ... import kernels as K
-from ..lora import Linear, gated_linear
+from ..lora import ActivationBudget, Linear, gated_linear
 from .configuration_cogvlm import CogVLMConfig
 from .visual import EVA2CLIPModel
 
@@ -227,10 +227,17 @@ class CogVLMModel(nn.Module):
         if feats is not None:
             x = Fh.overwrite_rows_(x, torch.cat(feats, dim=0).to(x.dtype), rt.row_of_tok[img_tok].contiguous())
         hs = [] if output_hidden_states else None
-        for layer in self.layers:
+        ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        n_keep = 0
+        if ckpt:
+            # saved per packed row and layer: ~8 hidden-width tensors, gate/up/silu·up (3 x intermediate), LoRA
+            # projections (7 x r); bf16
+            h, im = self.config.hidden_size, self.config.intermediate_size
+            n_keep = ActivationBudget.claim(len(self.layers), x.shape[0] * (8 * h + 3 * im + 7 * 64) * x.element_size())
+        for i, layer in enumerate(self.layers):
             if hs is not None:
                 hs.append(x)
-            if self.gradient_checkpointing and self.training:
+            if ckpt and i >= n_keep:
                 x = checkpoint(layer, x, rt, use_reentrant=False, preserve_rng_state=False)
             else:
                 x = layer(x, rt)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from ... import functional as Fh
-from ..lora import Linear
+from ..lora import ActivationBudget, Linear
 from ..resample import Downsample, resample
 
 
@@ -98,8 +98,16 @@ class Transformer(nn.Module):
         self.layers = nn.ModuleList([TransformerLayer(config) for _ in range(config.num_hidden_layers)])
 
     def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
-        for layer in self.layers:
-            if self.gradient_checkpointing and self.training:
+        ckpt = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        n_keep = 0
+        if ckpt:
+            # saved per row and layer: ~9 hidden-width tensors (LN/linear inputs, q/k/v, attention output), the fc1
+            # output and its GELU, the LoRA projections; bf16
+            l0 = self.layers[0]
+            d, f = l0.mlp.fc1.in_features, l0.mlp.fc1.out_features
+            n_keep = ActivationBudget.claim(len(self.layers), x.shape[0] * (9 * d + 2 * f + 4 * 64) * x.element_size())
+        for i, layer in enumerate(self.layers):
+            if ckpt and i >= n_keep:
                 x = checkpoint(layer, x, cu, max_len, use_reentrant=False, preserve_rng_state=False)
             else:
                 x = layer(x, cu, max_len)

@@ -52,6 +52,36 @@ class StepState:
         return (cls.seed * 1000003 + cls.step * 7919 + site * 104729) & 0x7FFFFFFFFFFFFFFF
 
 
+class ActivationBudget:
+    """How many transformer layers may keep their activations instead of being recomputed in backward.
+
+    The reference turns gradient checkpointing on for every layer (mmmm.py:232-233 via on_fit_start) because an 80 GB
+    device leaves no choice; the recompute is a quarter of the step's matrix work. With 288 GB of HBM3E the saved
+    activations of the whole VividMed step fit several times over, so checkpointing becomes a per-layer decision
+    against a byte budget: `claim()` hands each transformer the number of layers it may run un-checkpointed. Results
+    are identical either way (dropout masks are a pure function of (seed, step, site, element))."""
+    limit: int | None = None      # bytes; None = reference behaviour (checkpoint every layer)
+    remaining: int = 0
+    safety: float = 1.25
+    last_plan: list = []          # [(layers, kept)] of the current step, for logging
+
+    @classmethod
+    def reset(cls):
+        cls.remaining = cls.limit or 0
+        cls.last_plan = []
+
+    @classmethod
+    def claim(cls, n_layers: int, bytes_per_layer: int) -> int:
+        if cls.limit is None or bytes_per_layer <= 0:
+            cls.last_plan.append((n_layers, 0))
+            return 0
+        need = int(bytes_per_layer * cls.safety)
+        n = int(min(n_layers, cls.remaining // need))
+        cls.remaining -= n * need
+        cls.last_plan.append((n_layers, n))
+        return n
+
+
 class Linear(nn.Module):
     """y = x W^T (+ b) (+ s·B A drop(x)); frozen weights keep a transposed copy for the dgrad GEMM."""
 
@@ -64,6 +94,7 @@ class Linear(nn.Module):
         self.lora_B: nn.ModuleDict | None = None
         self.lora_cfg: LoraConfig | None = None
         self._wt: torch.Tensor | None = None
+        self._lora_t: tuple | None = None      # (At [in, r], Bt [r, out], version key) — see LoraTransposes
         self._site = StepState.new_site()
         nn.init.normal_(self.weight, std=0.02)
 
@@ -96,10 +127,20 @@ class Linear(nn.Module):
             self._wt = K.transpose(self.weight.detach())
         return self._wt
 
+    def lora_t(self):
+        """(At, Bt) resident transposed LoRA factors if `LoraTransposes.refresh()` ran after the last in-place
+        update of A/B (tensor version counters), else (None, None) and the backward transposes per use."""
+        c = self._lora_t
+        if c is not None and c[2] == (self.A._version, self.B._version, self.A.data_ptr(), self.B.data_ptr()):
+            return c[0], c[1]
+        return None, None
+
     def meta(self, gated: bool = False) -> Fh.LinearMeta:
         m = Fh.LinearMeta(gated=gated)
         if self.lora_cfg is not None:
             m.lora_scale = self.lora_cfg.scale
+            if torch.is_grad_enabled():
+                m.At0, m.Bt0 = self.lora_t()
             if self.training and self.lora_cfg.lora_dropout > 0:
                 m.drop_p = self.lora_cfg.lora_dropout
                 m.drop_seed = StepState.seed_for(self._site)
@@ -123,6 +164,8 @@ def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torc
     if language.lora_cfg is not None and vision.lora_cfg is None:
         raise NotImplementedError('LoRA on the language expert only')
     lora_l = language.lora_cfg is not None
+    if lora_l and torch.is_grad_enabled():
+        m.At1, m.Bt1 = language.lora_t()
     return Fh.linear(
         x, vision.weight, meta=m, Wt0=vision.wt() if need_dx else None, b0=vision.bias, A0=vision.A, B0=vision.B,
         W1=language.weight, Wt1=language.wt() if need_dx else None, b1=language.bias,
@@ -133,3 +176,50 @@ def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torc
 
 def _zero_like(t):
     return None if t is None else torch.zeros_like(t)
+
+
+class LoraTransposes:
+    """Resident K-contiguous copies (A^T [in, r], B^T [r, out]) of every LoRA factor below `root`, refreshed by ONE
+    launch (`vm_transpose_batched`) after each optimizer step. The backward of a LoRA linear needs both transposes
+    (dx += s·(dy B) A; functional._Linear.backward); doing them per use costs two tiny launches per linear per step
+    (~1.3k launches on the full VividMed model). Staleness is detected through the parameters' version counters, so a
+    forgotten `refresh()` only falls back to the per-use path, never to stale factors."""
+
+    def __init__(self, root: nn.Module):
+        self.linears = [m for m in root.modules() if isinstance(m, Linear) and m.lora_cfg is not None]
+        self.desc = None
+        self.n = 0
+        self.tiles = 1
+        self.dtype = None
+        self._ptrs = None
+
+    def _build(self):
+        rows = []
+        bufs = []
+        self.dtype = self.linears[0].A.dtype
+        for m in self.linears:
+            A, B = m.A, m.B
+            assert A.dtype == self.dtype and B.dtype == self.dtype, 'LoRA factors must share one dtype'
+            At = torch.empty(A.shape[1], A.shape[0], dtype=A.dtype, device=A.device)
+            Bt = torch.empty(B.shape[1], B.shape[0], dtype=B.dtype, device=B.device)
+            bufs.append((At, Bt))
+            for src, dst in ((A, At), (B, Bt)):
+                rows.append([src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.stride(0)])
+                self.tiles = max(self.tiles, min(64, -(-src.shape[0] // 64) * -(-src.shape[1] // 64)))
+        self.bufs = bufs
+        self.n = len(rows)
+        self.desc = torch.tensor(rows, dtype=torch.int64).to(self.linears[0].A.device)
+        self._ptrs = tuple(m.A.data_ptr() for m in self.linears) + tuple(m.B.data_ptr() for m in self.linears)
+
+    @torch.no_grad()
+    def refresh(self):
+        if not self.linears:
+            return
+        ptrs = tuple(m.A.data_ptr() for m in self.linears) + tuple(m.B.data_ptr() for m in self.linears)
+        if self.desc is None or ptrs != self._ptrs:
+            self._build()
+        for i in range(0, self.n, 65534):
+            n = min(65534, self.n - i)
+            K.transpose_batched(self.desc[i:i + n].contiguous() if i else self.desc, n, self.tiles, self.dtype)
+        for m, (At, Bt) in zip(self.linears, self.bufs):
+            m._lora_t = (At, Bt, (m.A._version, m.B._version, m.A.data_ptr(), m.B.data_ptr()))

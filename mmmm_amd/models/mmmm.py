@@ -18,7 +18,7 @@ from .. import functional as Fh
 from ..utils import apply_prefix, get_lora_modules_default, get_lora_modules_finetune_all
 from .cogvlm.configuration_cogvlm import CogVLMConfig
 from .cogvlm.modeling_cogvlm import CausalLMOutputWithPast, CogVLMForCausalLM
-from .lora import Linear, StepState
+from .lora import ActivationBudget, Linear, LoraTransposes, StepState
 from .loss import DiceFocalLoss
 
 __all__ = ['MMMMForCausalLM', 'build', 'VisionArgs', 'MyPrecision']
@@ -223,6 +223,10 @@ class MMMMForCausalLM(CogVLMForCausalLM):
     def training_step(self, batch: dict, *args, **kwargs):
         """mmmm.py:296-352"""
         StepState.step += 1
+        ActivationBudget.reset()
+        if getattr(self, '_lora_transposes', None) is None:
+            object.__setattr__(self, '_lora_transposes', LoraTransposes(self))
+        self._lora_transposes.refresh()          # one launch: K-contiguous LoRA factors for this step's backward
         vlm_inputs = batch['vlm_inputs']
         input_ids = vlm_inputs['input_ids']
         out: CausalLMOutputWithPast = self(**vlm_inputs, image=batch['image'], patch_size=batch['patch_size'],

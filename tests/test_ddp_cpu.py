@@ -99,3 +99,22 @@ def test_world1_keeps_grads_in_flat_buckets():
         p.grad = None          # optimizer.zero_grad(set_to_none=True)
     ddp.zero_grad()
     assert all(p.grad is not None for p in net.parameters() if p.requires_grad)
+
+
+def test_clip_grad_norm_on_buckets_matches_torch():
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    torch.manual_seed(1)
+    net = Net()
+    ddp = BucketedGradAllReduce(net.parameters(), world_size=1, bucket_bytes=2048)
+    ddp.zero_grad()
+    (net(torch.randn(7, 16), True) * 30).backward()
+    ddp.finish()
+    ref = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+    ref_norm = torch.nn.utils.clip_grad_norm_(ref_params := [torch.nn.Parameter(torch.zeros_like(g)) for g in ref], 1e9)
+    for rp, g in zip(ref_params, ref):
+        rp.grad = g.clone()
+    ref_norm = torch.nn.utils.clip_grad_norm_(ref_params, 1.0)
+    got = ddp.clip_grad_norm_(1.0)
+    torch.testing.assert_close(got, ref_norm, rtol=1e-5, atol=1e-6)
+    for p, rp in zip([p for p in net.parameters() if p.requires_grad], ref_params):
+        torch.testing.assert_close(p.grad, rp.grad, rtol=1e-5, atol=1e-7)

@@ -140,6 +140,22 @@ def test_transpose(dev, K):
         assert torch.equal(y[:, :100], x[:100].T) and torch.all(y[:, 100:] == 0)
 
 
+def test_transpose_batched(dev, K):
+    """one launch over a descriptor table of differently shaped matrices (the LoRA factors of a model)"""
+    for dt in (torch.bfloat16, torch.float32):
+        shapes = [(64, 4096), (4096, 64), (64, 1792), (5, 3), (130, 200), (64, 64)]
+        src = [torch.randn(r, c, device=dev).to(dt) for r, c in shapes]
+        dst = [torch.full((c, r), 7.0, device=dev, dtype=dt) for r, c in shapes]
+        desc = torch.tensor([[a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], a.stride(0), b.stride(0)]
+                             for a, b in zip(src, dst)], dtype=torch.int64).to(dev)
+        for tiles in (1, 7, 64):
+            for b in dst:
+                b.fill_(7.0)
+            K.transpose_batched(desc, len(src), tiles, dt)
+            for a, b in zip(src, dst):
+                assert torch.equal(b, a.T)
+
+
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('cols', [64, 4096])

@@ -175,3 +175,69 @@ def test_lora_dropout_mask_is_replayed(dev, lm):
             mod.lora_cfg.lora_dropout = 0.0
     lm.model.gradient_checkpointing = False
     lm.model.vision.transformer.gradient_checkpointing = False
+
+
+def _grads(lm, batch):
+    for p in lm.parameters():
+        p.grad = None
+    out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
+    out.loss.backward()
+    return out.loss.item(), {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}
+
+
+def test_activation_budget_keeps_some_layers_without_changing_gradients(dev, lm):
+    """HBM-budgeted checkpointing (ActivationBudget): any split between kept and recomputed layers is the same step"""
+    from mmmm_amd.models.lora import ActivationBudget
+    lm.train()
+    lm.gradient_checkpointing_enable()
+    batch, _ = make_inputs(dev, seed=11)
+    try:
+        ActivationBudget.limit = None
+        ActivationBudget.reset()
+        ref = _grads(lm, batch)
+        assert all(kept == 0 for _, kept in ActivationBudget.last_plan)
+        plans = []
+        for limit in (1 << 20, 1 << 40):
+            ActivationBudget.limit = limit
+            ActivationBudget.reset()
+            got = _grads(lm, batch)
+            plans.append(list(ActivationBudget.last_plan))
+            assert got[0] == ref[0]
+            for n in ref[1]:
+                assert torch.equal(got[1][n], ref[1][n]), n
+        assert all(kept == total for total, kept in plans[1]) and len(plans[1]) == 2
+        assert sum(kept for _, kept in plans[0]) < sum(kept for _, kept in plans[1])
+    finally:
+        ActivationBudget.limit = None
+        lm.model.gradient_checkpointing = False
+        lm.model.vision.transformer.gradient_checkpointing = False
+
+
+def test_resident_lora_transposes_match_per_use_transposes(dev, lm):
+    from mmmm_amd.models.lora import Linear, LoraTransposes
+    lm.train()
+    batch, _ = make_inputs(dev, seed=13)
+    mods = [m for m in lm.modules() if isinstance(m, Linear) and m.lora_cfg is not None]
+    for m in mods:
+        m._lora_t = None
+    ref = _grads(lm, batch)
+    cache = LoraTransposes(lm)
+    cache.refresh()
+    assert len(cache.linears) == len(mods) and all(m.lora_t()[0] is not None for m in mods)
+    for m in mods:
+        At, Bt = m.lora_t()
+        assert torch.equal(At, m.A.detach().t()) and torch.equal(Bt, m.B.detach().t())
+    got = _grads(lm, batch)
+    assert got[0] == ref[0]
+    for n in ref[1]:
+        assert torch.equal(got[1][n], ref[1][n]), n
+    # an in-place parameter update invalidates the cached copies until the next refresh()
+    with torch.no_grad():
+        mods[0].A.mul_(1.5)
+    assert mods[0].lora_t() == (None, None) and mods[1].lora_t()[0] is not None
+    cache.refresh()
+    assert torch.equal(mods[0].lora_t()[0], mods[0].A.detach().t())
+    with torch.no_grad():
+        mods[0].A.div_(1.5)
+    for m in mods:
+        m._lora_t = None
