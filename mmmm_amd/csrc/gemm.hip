@@ -159,11 +159,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   };
   auto ext_scale = [&]() {
     // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the forward's LoRA input
+    if (p.drop_p > 0.f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        gemm_ext_scale4(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
+        for (int j = 0; j < 4; ++j)
+          gemm_ext_scale4<true>(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= p.alpha2;
+    }
   };
   const std::true_type T_{};
   const std::false_type F_{};
@@ -208,6 +215,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     typedef EpiSlab<64, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
     const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
+    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
+    if (fast_bias) {
+      f32x4_t bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = epi_bias4(bias, n0 + wn * 64 + i * 16 + fq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          epi_put4<2>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, 0, 4, acc[i][j], bv[i]);
+    } else
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -300,7 +318,9 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
 
 extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, void* stream);
 
-// 256x256 tiles when they fill the 256 CUs well (>= 80 % of the last round), 128x128 tiles otherwise.
+// Tile choice by estimated rounds over the 256 CUs. Measured on MI355X (tools/bench_gemm_vit.py): one round of 256x256
+// tiles (1 workgroup per CU) costs about 3.0x one round-equivalent of 128x128 tiles (2 co-resident workgroups per CU
+// retire 256 tiles per unit), so 256x256 wins whenever ceil(T256/256) * 3 <= ceil(T128/256).
 // VM_GEMM_TILE=128|256 forces a choice (tests / A-B measurements).
 static bool use_tile256(int M, int N, int K, bool segmented) {
   static int forced = -1;
@@ -311,9 +331,9 @@ static bool use_tile256(int M, int N, int K, bool segmented) {
   if (forced == 128) return false;
   if (forced == 256) return true;
   if (K < 128) return false;
-  const int t = ((M + 255) / 256 + (segmented ? 1 : 0)) * ((N + 255) / 256);
-  const int rounds = (t + 255) / 256;
-  return (float)t / (float)(rounds * 256) >= 0.80f;
+  const int64_t t256 = (int64_t)((M + 255) / 256 + (segmented ? 1 : 0)) * ((N + 255) / 256);
+  const int64_t t128 = (int64_t)((M + 127) / 128 + (segmented ? 1 : 0)) * ((N + 127) / 128);
+  return ((t256 + 255) / 256) * 3 <= (t128 + 255) / 256;
 }
 
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {

@@ -168,11 +168,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     __builtin_amdgcn_s_barrier();
   };
   auto ext_scale = [&]() {
+    if (p.drop_p > 0.f) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        gemm_ext_scale4(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+        for (int j = 0; j < 4; ++j)
+          gemm_ext_scale4<true>(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= p.alpha2;
+    }
   };
 
   // prologue: K-tile 0 completely
@@ -181,12 +188,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();
 
-  for (int t = 0; t + 1 < kt_total; ++t) {
-    ktile(t, std::true_type{});
-    if (t + 1 == kt_ext) ext_scale();
+  // extension tiles (LoRA rank slab; the main K always follows), the scale between the two loops — never inside one:
+  // with the scale in the loop body the compiler hoists the 128 loop-invariant mask hashes and spills them
+  int t = 0;
+  if (kt_ext > 0) {
+    for (; t < kt_ext; ++t) ktile(t, std::true_type{});
+    ext_scale();
   }
+  for (; t + 1 < kt_total; ++t) ktile(t, std::true_type{});
   ktile(kt_total - 1, std::false_type{});
-  if (kt_total == kt_ext) ext_scale();
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
   if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
@@ -208,9 +218,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     typedef EpiSlab<64, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
     const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
+    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
+    f32x4_t bv[4];
+    if (fast_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = epi_bias4(bias, n0 + wn * 64 + j * 16 + fq * 4);
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      if (plain) {
+      if (fast_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j], bv[j]);
+      } else if (plain) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -69,11 +69,12 @@ __device__ __forceinline__ void gemm_tile_rows(const GemmParams& p, int tm, int&
   }
 }
 
-// LoRA-extension post-scale of a lane's 4 consecutive-n accumulator registers (+ dgrad dropout mask)
+// LoRA-extension post-scale of a lane's 4 consecutive-n accumulator registers (+ dgrad dropout mask).
+// DROP is a compile-time flag: the caller branches ONCE on p.drop_p around the whole accumulator sweep.
+template <bool DROP>
 __device__ __forceinline__ void gemm_ext_scale4(const GemmParams& p, int64_t m, int n, f32x4_t& a) {
   const float a2 = p.alpha2;
-  const bool drop = p.drop_p > 0.f;
-  if (!drop) { a *= a2; return; }
+  if (!DROP) { a *= a2; return; }
   const float inv_keep = 1.0f / (1.0f - p.drop_p);
   const uint64_t hsh = vm_hash4(p.drop_seed, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
   const unsigned thr = vm_drop_threshold(p.drop_p);
@@ -135,15 +136,25 @@ struct EpiSlab {
   static constexpr int BYTES = ROWS * PITCH;
 };
 
+// bf16 bias of a lane's 4 consecutive columns as floats (interior column group, 8-byte aligned bias pointer)
+__device__ __forceinline__ f32x4_t epi_bias4(const void* bias, int n) {
+  const u16x4_t b = *reinterpret_cast<const u16x4_t*>((const unsigned short*)bias + n);
+  return (f32x4_t){bf2f(b[0]), bf2f(b[1]), bf2f(b[2]), bf2f(b[3])};
+}
+
 // write one lane-owned group (row r, cols c..c+3 of the slab) after bias + activation.
-// MODE 0: no bias, no activation (the common case: no per-element branches at all); MODE 1: generic.
+// MODE 0: no bias, no activation (no per-element branches at all); MODE 2: bias pre-loaded by the caller into `bv`
+// (one 8-byte load per column group, reused for every row tile), no activation; MODE 1: generic.
 template <int MODE>
 __device__ __forceinline__ void epi_put4(char* slab, int pitch, int r, int c, const GemmParams& p, const void* bias, int n,
-                                         int ncols_left, const f32x4_t& acc) {
+                                         int ncols_left, const f32x4_t& acc, const f32x4_t bv = (f32x4_t){0.f, 0.f, 0.f, 0.f}) {
   u16x4_t o;
   if (MODE == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e]);
+  } else if (MODE == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e] + bv[e]);
   } else {
     const unsigned short* bp = (const unsigned short*)bias;
 #pragma unroll
@@ -171,17 +182,21 @@ __device__ __forceinline__ void epi_flush(const char* slab, const GemmParams& p,
   const unsigned short* rp = (const unsigned short*)p.residual;
   const bool vec_ok = (p.ldc % 8 == 0) && (n0 % 8 == 0) && (!rp || p.ldr % 8 == 0);
   if (p.dbg & 64) return;                       // timing experiment: epilogue without stores
-  if (vec_ok && rows_valid >= ROWS && cols_valid >= COLS) {
+  if (vec_ok && cols_valid >= COLS) {
+    // full-width column block: whole 16-byte chunks; a ragged last row tile only predicates rows
     unsigned short* cbase = (unsigned short*)p.C + (m0 + rr) * p.ldc + n0 + ch * 8;
     const char* sbase = slab + rr * PITCH + ch * 16;
+    const int rlim = rows_valid - rr;            // iteration `it` is live iff it * RPI < rlim
     if (!rp) {
 #pragma unroll
       for (int it = 0; it < ROWS / RPI; ++it)
-        *reinterpret_cast<u16x8_t*>(cbase + (int64_t)it * RPI * p.ldc) = *reinterpret_cast<const u16x8_t*>(sbase + it * RPI * PITCH);
+        if (it * RPI < rlim)
+          *reinterpret_cast<u16x8_t*>(cbase + (int64_t)it * RPI * p.ldc) = *reinterpret_cast<const u16x8_t*>(sbase + it * RPI * PITCH);
     } else {
       const unsigned short* rbase = rp + (m0 + rr) * p.ldr + n0 + ch * 8;
 #pragma unroll
       for (int it = 0; it < ROWS / RPI; ++it) {
+        if (it * RPI >= rlim) continue;
         u16x8_t v = *reinterpret_cast<const u16x8_t*>(sbase + it * RPI * PITCH);
         const u16x8_t rv = *reinterpret_cast<const u16x8_t*>(rbase + (int64_t)it * RPI * p.ldr);
 #pragma unroll
