@@ -204,6 +204,8 @@ def main():
                     help="'reference': recompute every transformer layer in backward (mmmm.py:232-233); 'hbm': keep the "
                          "activations of as many layers as the free HBM of this device holds (same results, less recompute)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--all-kernel-events', action='store_true',
+                    help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     args = ap.parse_args()
 
@@ -259,7 +261,7 @@ def main():
     use_events = not args.no_kernel_events
     if use_events:
         K.prof_reset()
-        K.prof_enable(True)
+        K.prof_enable(True if args.all_kernel_events else (hip.PROF_GEMM_BF16,))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -49,10 +49,10 @@ int vm_version(void);
 int vm_device_arch(char* name_host, int len);
 
 /* per-kernel profiling with HIP events (used by bench.py for `roofline`).
- * When enabled, every vm_gemm_* launch is bracketed by two events recorded on
- * the launch stream; vm_prof_collect synchronises those events and returns the
+ * When enabled for a kind, every launch of that kind is bracketed by two events recorded on
+ * the launch stream (two hipEventRecord per launch: enable only the kinds you report); vm_prof_collect synchronises those events and returns the
  * summed duration and the summed algorithmic FLOPs. */
-int vm_prof_enable(int on);
+int vm_prof_enable(int kind_mask);   /* bit k set: bracket launches of kind VM_PROF_* == k; 0 disables */
 int vm_prof_reset(void);
 int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, int64_t* launches_host);
 #define VM_PROF_GEMM_BF16 0
@@ -120,6 +120,10 @@ typedef struct vm_gemm_args {
   int32_t out_dtype;                         /* VM_BF16 or VM_F32 */
   float drop_p; uint64_t drop_seed;          /* dropout on the extension accumulator */
   float alpha;                               /* scale on the main product (1.0 default) */
+  int32_t ksplit;                            /* > 1: split K over that many workgroups per tile and ACCUMULATE into a
+                                                pre-zeroed fp32 C with atomics (tiny M x N, long K: the weight gradients of
+                                                the mask-decoder hyper-network products). Needs out_dtype VM_F32, no
+                                                activation, K2 == 0. 0 / 1 = off. */
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);
@@ -127,9 +131,13 @@ int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);
 /* LoRA down-projection (peft lora.Linear, conf/lora.yaml r = 64): t[M,64] = drop(x)[M,K] · A[64,K]^T with the
  * inverted dropout of lora_dropout fused on the activation fragment ((seed, row*K+col) hash, same mask as
  * vm_dropout). Also computes u = dy · B in the backward (A = B^T). Optional two row segments (gated experts):
- * rows [0,split) use A0, rows [split,M) use A1; split / M from counts_dev when non-NULL. R must be 64, K % 128 == 0. */
+ * rows [0,split) use A0, rows [split,M) use A1; split / M from counts_dev when non-NULL. R must be 64, K % 8 == 0. */
 int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
-                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed, void* stream);
+                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+/* fp32 scratch the K-split form of vm_lora_down wants for (M, K) (0: none). Without it the kernel runs one pass per
+ * 64-row block, which is correct but leaves most CUs idle for M << 16k. The split sum order is fixed (deterministic). */
+int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host);
 
 /* Row-contraction ("TN") bf16 GEMM for weight gradients: C[P,Q] = alpha * X[M,P]^T · drop(Y)[M,Q] contracted over
  * token rows — dB = dy^T t, dA = u^T drop(x), dW = dy^T x of peft lora.Linear / trainable nn.Linear. Operands stay

@@ -62,11 +62,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 
   // ---- buffer resources (wave-uniform): OOB rows read as zero
   const int lda_b = (int)p.lda * ESZ, ldb_b = (int)p.ldb * ESZ;
-  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
-  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
+  const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;              // split-K: this workgroup's K range
+  const int kloc = p.ksplit > 1 ? min(p.kchunk, p.K - kbeg) : p.K;
+  const int kskip = kbeg * ESZ;
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b + kskip, (p.dbg & 1) ? 0 : nrows * lda_b - kskip);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b + kskip, (p.dbg & 1) ? 0 : ncols * ldb_b - kskip);
 
   const int kt_ext = p.K2 / BKE;
-  const int kt_main = p.K / BKE;
+  const int kt_main = kloc / BKE;
   const int kt_total = kt_ext + kt_main;
 
   __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
+    const bool splitk = p.ksplit > 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ml = wm * 64 + j * 16 + frow;
@@ -207,7 +211,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
       for (int i = 0; i < 4; ++i) {
         const int nl = wn * 64 + i * 16 + fq * 4;
         if (nl >= ncols) continue;
-        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+        if (!splitk) { gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]); continue; }
+        // split-K partial: atomically accumulated; bias / residual enter once, with the first K range
+        float* cp = (float*)p.C + (int64_t)(row0 + ml) * p.ldc + n0 + nl;
+        for (int r = 0; r < 4 && r < ncols - nl; ++r) {
+          float x = acc[i][j][r];
+          if (blockIdx.y == 0) {
+            if (bias) x += ((const float*)bias)[n0 + nl + r];
+            if (p.residual) x += ((const float*)p.residual)[(int64_t)(row0 + ml) * p.ldr + n0 + nl + r];
+          }
+          atomicAdd(cp + r, x);
+        }
       }
     }
   } else {
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 struct ProfRec { hipEvent_t a, b; double flops; };
 struct ProfState {
   std::mutex mu;
-  bool on = false;
+  unsigned mask = 0;       // bit k: bracket launches of kind k
   std::vector<ProfRec> recs[4];
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -254,7 +268,7 @@ ProfState& prof() { static ProfState s; return s; }
 // shared with the other translation units
 extern "C" int vm_prof_begin_(int kind, void* stream, void** tok) {
   ProfState& s = prof();
-  if (!s.on) { *tok = nullptr; return 0; }
+  if (!((s.mask >> kind) & 1u)) { *tok = nullptr; return 0; }
   std::lock_guard<std::mutex> lk(s.mu);
   ProfRec r;
   if (!s.pool.empty()) { r.a = s.pool.back().first; r.b = s.pool.back().second; s.pool.pop_back(); }
@@ -290,7 +304,7 @@ int vm_device_arch(char* name_host, int len) {
   return VM_OK;
 }
 
-int vm_prof_enable(int on) { prof().on = on != 0; return VM_OK; }
+int vm_prof_enable(int kind_mask) { prof().mask = (unsigned)kind_mask & 0xFu; return VM_OK; }
 
 int vm_prof_reset(void) {
   ProfState& s = prof();
@@ -367,6 +381,14 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   p.split = segmented ? (a->counts_dev ? 0 : a->split) : -1;
   p.act = a->act;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
+  p.ksplit = 1; p.kchunk = a->K;
+  if (a->ksplit > 1) {
+    if (a->out_dtype != VM_F32 || a->act != VM_ACT_NONE || a->K2 != 0) return VM_ERR_BAD_ARG;
+    const int kt = a->K / bke;
+    const int per = (kt + a->ksplit - 1) / a->ksplit;
+    p.kchunk = per * bke;
+    p.ksplit = (kt + per - 1) / per;
+  }
   p.tiles_m = (a->M + BM - 1) / BM + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
@@ -375,13 +397,13 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
-  if (esz == 2 && use_tile256(a->M, a->N, a->K + a->K2, segmented)) {
+  if (esz == 2 && p.ksplit <= 1 && use_tile256(a->M, a->N, a->K + a->K2, segmented)) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, stream);
     if (rc != VM_OK) return rc;
   } else if (esz == 4)
-    hipLaunchKernelGGL((gemm_nt_k<4, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_nt_k<4, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else if (a->out_dtype == VM_F32)
-    hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((gemm_nt_k<2, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   vm_prof_end_(kind, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2));

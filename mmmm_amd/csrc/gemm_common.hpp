@@ -20,6 +20,7 @@ struct GemmParams {
   int act;
   float drop_p; uint64_t drop_seed;
   int tiles_m, tiles_n;
+  int ksplit, kchunk;   // split-K (fp32 atomics into a zeroed C): blockIdx.y owns K range [y*kchunk, (y+1)*kchunk)
   int dbg;   // timing experiments only: bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
 };
 

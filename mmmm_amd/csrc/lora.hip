@@ -33,14 +33,24 @@ struct DownP {
   int M, K;
   const int32_t* counts_dev; int split;
   float drop_p; uint64_t seed;
+  float* ws; int ksplits;                   // fp32 partials [ksplits][M][64] when ksplits > 1
 };
 
-// 8 waves per 16-row slab: wave w takes the 32-wide k-steps w, w+8, w+16, ... (any K % 32 == 0), 4 k-steps of loads in
-// flight per wave; partial sums are reduced through LDS. (4 waves / contiguous K quarters left the chip at ~3.5 waves
-// per CU and latency bound: 57 us per call at M=3648, K=4096.)
-constexpr int DOWN_WAVES = 8;
-__global__ __launch_bounds__(DOWN_WAVES * 64) void lora_down_k(const DownP p) {
-  __shared__ float red[DOWN_WAVES][16][64 + 1];
+// Streaming skinny GEMM: a workgroup owns 64 rows x one K range. x (the HBM stream) and the 64 x K factor slice are
+// staged per 128-wide K-tile through LDS-DMA (whole 256-byte row segments, 2 stages, 2 workgroups per CU), so the factor
+// is fetched from L2 once per 64 rows instead of once per 16 (the earlier one-slab-per-workgroup form moved 4 bytes of A
+// through L2 for every byte of x and sat at ~1.1 TB/s). Wave w multiplies rows 16w..16w+15 by all 64 factor rows with
+// v_mfma_f32_16x16x32_bf16; the dropout mask is applied to the x fragment in registers, once per element.
+// K is split over blockIdx.y to fill the chip; partial sums go to an fp32 workspace and are reduced in a FIXED order by
+// lora_reduce_k (deterministic, no atomics).
+constexpr int DN_BM = 64;
+constexpr int DN_STAGE = 2 * DN_BM * ROWB;     // x tile + A tile
+
+__device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
+                                           int col0, int cols_total, char* tile, int wave, int lane);
+
+__global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * DN_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int M = p.M, split = p.split;
@@ -50,76 +60,98 @@ __global__ __launch_bounds__(DOWN_WAVES * 64) void lora_down_k(const DownP p) {
   }
   int row0, nrows, seg = 0;
   const int tb = blockIdx.x;
-  if (split < 0) { row0 = tb * 16; nrows = min(16, M - row0); }
+  if (split < 0) { row0 = tb * DN_BM; nrows = min(DN_BM, M - row0); }
   else {
     split = min(split, M);
-    const int t0 = (split + 15) / 16;
-    if (tb < t0) { row0 = tb * 16; nrows = min(16, split - row0); }
-    else { seg = 1; row0 = split + (tb - t0) * 16; nrows = min(16, M - row0); }
+    const int t0 = (split + DN_BM - 1) / DN_BM;
+    if (tb < t0) { row0 = tb * DN_BM; nrows = min(DN_BM, split - row0); }
+    else { seg = 1; row0 = split + (tb - t0) * DN_BM; nrows = min(DN_BM, M - row0); }
   }
   if (nrows <= 0) return;
   const unsigned short* A = seg ? p.A1 : p.A0;
   const int frow = lane & 15, fq = lane >> 4;
-  const bool rvalid = frow < nrows;
-  const int64_t m = row0 + frow;
-  const unsigned short* xr = p.x + (rvalid ? m : row0) * p.ldx;
+  const int kt_total = (p.K + 127) / 128;
+  const int per = (kt_total + p.ksplits - 1) / p.ksplits;
+  const int kt0 = blockIdx.y * per, kt1 = min(kt_total, kt0 + per);
+  if (kt0 >= kt1) return;      // (the host sizes ksplits so that every split is non-empty)
+
   const bool drop = p.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(p.drop_p);
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  const int nsteps = p.K / 32;
+  const int64_t m = row0 + wave * 16 + frow;
+
+  auto stage = [&](int kt, int buf) {
+    char* sx = smem + buf * DN_STAGE;
+    char* sa = sx + DN_BM * ROWB;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      stage_rows(p.x, p.ldx, row0 + 32 * hlf, max(0, nrows - 32 * hlf), kt * 128, p.K, sx + hlf * 32 * ROWB, wave, lane);
+      stage_rows(A, p.lda, 32 * hlf, 32, kt * 128, p.K, sa + hlf * 32 * ROWB, wave, lane);
+    }
+  };
 
   f32x4_t acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  auto load_x = [&](int step) -> u16x8_t {
-    u16x8_t xv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (rvalid && step < nsteps) xv = *reinterpret_cast<const u16x8_t*>(xr + step * 32 + 8 * fq);
-    return xv;
-  };
-  for (int s0 = wave; s0 < nsteps; s0 += DOWN_WAVES * 4) {
-    u16x8_t xv[4];
-    bf16x8_t wa[4][4];
+  stage(kt0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+    const char* sx = smem + buf * DN_STAGE;
+    const char* sa = sx + DN_BM * ROWB;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int step = s0 + u * DOWN_WAVES;
-      xv[u] = load_x(step);
-      const int kk = min(step, nsteps - 1) * 32 + 8 * fq;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wa[u][i] = *reinterpret_cast<const bf16x8_t*>(A + (int64_t)(16 * i + frow) * p.lda + kk);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int step = s0 + u * DOWN_WAVES;
-      if (step >= nsteps) break;
-      const int kk = step * 32 + 8 * fq;
+    for (int s = 0; s < 4; ++s) {
+      u16x8_t xv = *reinterpret_cast<const u16x8_t*>(sx + tile_off(wave * 16 + frow, 4 * s + fq));
       if (drop) {
+        const int kk = kt * 128 + 32 * s + 8 * fq;
         const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
         const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e)   // same rounding as the standalone dropout kernel: bf16(x * 1/(1-p))
-          xv[u][e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(xv[u][e]) * inv_keep) : (unsigned short)0;
+          xv[e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(xv[e]) * inv_keep) : (unsigned short)0;
       }
-      const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv[u]);
+      const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u][i], xb, acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const bf16x8_t wa = *reinterpret_cast<const bf16x8_t*>(sa + tile_off(16 * i + frow, 4 * s + fq));
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[i], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // D[row = r][col = m_local]: lane holds r = 16 i + 4 fq + 0..3 for row m
+  if (wave * 16 + frow >= nrows) return;
+  if (p.ksplits > 1) {
+    float* w = p.ws + ((int64_t)blockIdx.y * p.M + m) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(w + 16 * i + 4 * fq) = acc[i];
+  } else {
+    unsigned short* o = p.t + m * p.ldt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u16x4_t v = {f2bf(acc[i][0]), f2bf(acc[i][1]), f2bf(acc[i][2]), f2bf(acc[i][3])};
+      *reinterpret_cast<u16x4_t*>(o + 16 * i + 4 * fq) = v;
     }
   }
-  // D[row = r_local][col = m_local]: lane holds r = 16 i + 4 fq + e for m = frow
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][frow][16 * i + 4 * fq + e] = acc[i][e];
-  __syncthreads();
-  // 16 x 64 outputs over 512 threads: 2 consecutive r per thread
-  const int om = tid >> 5, orr = (tid & 31) * 2;
-  if (om < nrows) {
-    float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-    for (int w = 0; w < DOWN_WAVES; ++w) { v0 += red[w][om][orr]; v1 += red[w][om][orr + 1]; }
-    const unsigned packed = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-    *reinterpret_cast<unsigned*>(p.t + (int64_t)(row0 + om) * p.ldt + orr) = packed;
-  }
+}
+
+// t[m][0..63] = bf16(sum over splits, in split order, of ws[s][m][0..63]); one thread per 4 consecutive outputs
+__global__ __launch_bounds__(256) void lora_reduce_k(const float* __restrict__ ws, unsigned short* __restrict__ t, int64_t ldt,
+                                                     int M, int ksplits, const int32_t* counts_dev) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t m = g >> 4;
+  const int c = (int)(g & 15) * 4;
+  int rows = M;
+  if (counts_dev) rows = min(M, counts_dev[1]);
+  if (m >= rows) return;
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(ws + m * 64 + c);
+  for (int s = 1; s < ksplits; ++s) a += *reinterpret_cast<const f32x4_t*>(ws + ((int64_t)s * M + m) * 64 + c);
+  const u16x4_t v = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+  *reinterpret_cast<u16x4_t*>(t + m * ldt + c) = v;
 }
 
 // ============================================================================ vm_gemm_tn
@@ -269,11 +301,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
 
 extern "C" {
 
+// K-splits the kernel will use for (M, K): enough workgroups for two per CU, at least two K-tiles per split
+static int lora_down_ksplits(int M, int K, bool segmented) {
+  const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
+  const int kt = (K + 127) / 128;
+  int want = (512 + m_tiles - 1) / m_tiles;
+  want = max(1, min(want, kt / 2));
+  const int per = (kt + want - 1) / want;
+  return (kt + per - 1) / per;
+}
+
+int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host) {
+  if (!bytes_host || M < 0 || K <= 0) return VM_ERR_BAD_ARG;
+  const int s = M > 0 ? lora_down_ksplits(M, K, segmented != 0) : 1;
+  *bytes_host = s > 1 ? (int64_t)s * M * 64 * 4 : 0;
+  return VM_OK;
+}
+
 int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
-                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed, void* stream) {
+                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !A0 || !t) return VM_ERR_BAD_ARG;
   if (M <= 0) return VM_OK;
-  if (R != 64 || K % 32 || ldx % 8 || lda % 8 || ldt % 2) return VM_ERR_UNSUPPORTED;
+  if (R != 64 || K % 8 || K < 8 || ldx % 8 || lda % 8 || ldt % 4) return VM_ERR_UNSUPPORTED;
+  if ((int64_t)32 * ldx * 2 + 256 >= (1ll << 31) || (int64_t)32 * lda * 2 + 256 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
   const bool segmented = counts_dev != nullptr || split >= 0;
   if (segmented && !A1) return VM_ERR_BAD_ARG;
   DownP p;
@@ -284,10 +335,16 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   p.counts_dev = counts_dev;
   p.split = segmented ? (counts_dev ? 0 : split) : -1;
   p.drop_p = drop_p; p.seed = drop_seed;
-  const int grid = (M + 15) / 16 + (segmented ? 1 : 0);
+  p.ksplits = lora_down_ksplits(M, K, segmented);
+  p.ws = (float*)workspace;
+  if (p.ksplits > 1 && (!workspace || workspace_bytes < (int64_t)p.ksplits * M * 64 * 4)) p.ksplits = 1;   // no workspace: single pass
+  const int grid = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  hipLaunchKernelGGL(lora_down_k, dim3(grid), dim3(DOWN_WAVES * 64), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(lora_down_k, dim3(grid, p.ksplits), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.ksplits > 1)
+    hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)p.ws, p.t, p.ldt, M, p.ksplits, counts_dev);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * M * 64.0 * K);
   VM_LAUNCH_CHECK();
   return VM_OK;

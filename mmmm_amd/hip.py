@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ('out_dtype', C.c_int32),
         ('drop_p', C.c_float), ('drop_seed', C.c_uint64),
         ('alpha', C.c_float),
+        ('ksplit', C.c_int32),
     ]
 
 

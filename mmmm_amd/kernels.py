@@ -6,6 +6,7 @@ Every function enqueues on the current torch stream and returns immediately; the
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import torch
 
@@ -48,10 +49,16 @@ def gemm(
     assert w.dtype == a.dtype
     if out_dtype is None:
         out_dtype = a.dtype
+    # tiny M x N with a long contraction (weight gradients of the hyper-network mask products): one tile would walk
+    # all of K alone, so K is split over workgroups that accumulate into a zeroed fp32 C
+    ksplit = 0
+    if (out is None and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
+            and ((M + 127) // 128) * ((N + 127) // 128) <= 8 and K >= 1024):
+        ksplit = min(64, K // (4 * (32 if f32 else 64)))
     if out is None:
         al = 8 if out_dtype == torch.bfloat16 else 4
         Np = (N + al - 1) // al * al                 # keep ldc aligned for the vector stores of the epilogue
-        out = torch.empty(M, Np, dtype=out_dtype, device=a.device)
+        out = (torch.zeros if ksplit > 1 else torch.empty)(M, Np, dtype=out_dtype, device=a.device)
         if Np != N:
             out = out[:, :N]
     g = hip.GemmArgs()
@@ -81,6 +88,7 @@ def gemm(
     g.out_dtype = dtype_code(out.dtype)
     g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF
     g.alpha = 1.0
+    g.ksplit = ksplit
     hip.call('vm_gemm_f32' if f32 else 'vm_gemm_bf16', C.addressof(g), stream())
     return out
 
@@ -123,16 +131,26 @@ def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
 
 def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None, *, counts: torch.Tensor | None = None,
               split: int = -1, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
-    """t[M,64] = drop(x) @ A^T (bf16; rank 64; K % 128 == 0)"""
+    """t[M,64] = drop(x) @ A^T (bf16; rank 64; K % 8 == 0)"""
     M, Kd = x.shape
     t = torch.empty(M, A0.shape[0], dtype=x.dtype, device=x.device)
+    segmented = counts is not None or split >= 0
+    nbytes = _lora_ws_bytes(M, Kd, segmented)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
     hip.call('vm_lora_down', ptr(x), _ld(x), ptr(A0), ptr(A1), _ld(A0), ptr(t), _ld(t), M, Kd, A0.shape[0], ptr(counts), split,
-             drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, stream())
+             drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, ptr(ws), nbytes, stream())
     return t
 
 
+@functools.lru_cache(maxsize=256)
+def _lora_ws_bytes(M: int, Kd: int, segmented: bool) -> int:
+    n = C.c_int64(0)
+    hip.call('vm_lora_down_workspace', M, Kd, int(segmented), C.addressof(n))
+    return n.value
+
+
 def lora_down_supported(x: torch.Tensor, A: torch.Tensor) -> bool:
-    return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 32 == 0
+    return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 8 == 0 and x.shape[1] >= 8
 
 
 def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = None, segment: int = -1,
@@ -145,8 +163,9 @@ def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = N
     out_dtype = out_dtype or X.dtype
     tiles = ((P + 127) // 128) * ((Q + 127) // 128)
     splits = 1
-    if tiles < 128 and M >= 256:
-        splits = max(1, min(16, 256 // tiles, M // 128))
+    if tiles < 512 and M >= 256:
+        # row-contraction of a skinny product streams X and Y once: it wants >= 2-4 workgroups per CU in flight
+        splits = max(1, min(64, 1024 // tiles, M // 64))
     if splits > 1:
         C32 = torch.zeros(P, Q, dtype=torch.float32, device=X.device)
         hip.call('vm_gemm_tn_bf16', ptr(X), _ld(X), P, ptr(Y), _ld(Y), Q, ptr(C32), Q, VM_F32_, M, ptr(counts), segment, ptr(nrows),
@@ -393,8 +412,10 @@ def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim,
 
 
 # ------------------------------------------------------------------ profiling helpers
-def prof_enable(on: bool):
-    hip.call('vm_prof_enable', int(on))
+def prof_enable(kinds=True):
+    """kinds: True (every kind), False / () (off) or an iterable of hip.PROF_* kinds"""
+    mask = 0xF if kinds is True else 0 if not kinds else sum(1 << int(k) for k in kinds)
+    hip.call('vm_prof_enable', mask)
 
 
 def prof_reset():
