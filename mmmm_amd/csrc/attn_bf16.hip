@@ -459,6 +459,433 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_k(const AttnP p) {
     }
 }
 
+// =====================================================================================================================
+// 16-wide kernels (production path). A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV) and works with
+// v_mfma_f32_16x16x32_bf16, so its register footprint is about half that of the 32-wide kernels above: 16 waves per CU
+// instead of 4-8, and the MFMA, VALU (softmax) and LDS phases of different waves overlap by thread-level parallelism.
+// Operand tiles are staged by LDS-DMA (buffer_load ... lds, swizzle applied to the source chunk) into a 2-stage ring,
+// one barrier per 64-position tile; the tile after next's physical rows (packed-layout indirection) are fetched one
+// iteration ahead. Score tiles are kept transposed (key on the MFMA row, query on the lane) exactly as above.
+constexpr int OOB_OFF = 0x7FFFFFF0;
+constexpr int A16_STAGE = 2 * 64 * ROWB;         // two 64-row operand tiles per stage
+constexpr int A16_LDS = 2 * A16_STAGE;
+constexpr int A16_LDS_DKV = A16_LDS + 2 * 2 * 64 * 4;   // + [stage][lse|delta][64] floats
+
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const void* base) {
+  const uint64_t a = (uint64_t)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, OOB_OFF, 0x00020000);
+}
+
+// Chunk swizzle of the 256-byte-row tiles read by the 16-wide kernels: slot = chunk ^ ((row & 7) << 1).
+// Conflict-free for BOTH access patterns (bank rule: 16-byte slot s of a row occupies banks 4s..4s+3 of the 256-B bank row):
+//  * ds_read_b128 row fragments, lane (ln, g) -> (row 16j + ln, chunk 4s + g): inside each of the instruction's four
+//    16-lane groups the slots (4s + g) ^ 2(ln & 7) are 16 distinct values (the groups pair g = 0 with 1 and 2 with 3);
+//  * ds_read_b64_tr_b16, whose 32-lane half touches rows rbase + 0..7 (or 8..15), 32 contiguous bytes each at slot pair
+//    (2b ^ 2(row & 7)): eight distinct pairs.
+// (The 32-wide image swz() is 2-way conflicted under both of these patterns: measured SQ_LDS_BANK_CONFLICT 2.3x the
+// LDS instruction cycles.)
+__device__ __forceinline__ int swz16(int row) { return (row & 7) << 1; }
+__device__ __forceinline__ int tile_off16(int row, int chunk) { return row * ROWB + ((chunk ^ swz16(row)) << 4); }
+
+// A/B operand of a 16x16x32 MFMA read along rows: lane -> row r0 + (lane & 15), k = 32 s + 8 (lane >> 4) + 0..7
+__device__ __forceinline__ bf16x8_t frag16_row(const char* tile, int r0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + tile_off16(r0 + (lane & 15), 4 * s + (lane >> 4)));
+}
+// transposed operand: lane (i = lane & 15, g = lane >> 4) gets tile[rbase + 4 g + 0..3][16 b + i] and
+// tile[rbase + 16 + 4 g + 0..3][16 b + i] — the k order in which two stacked 16x16 accumulator tiles
+// (registers 0..3 of rows 4g.. and of rows 16 + 4g..) appear as the other operand.
+__device__ __forceinline__ bf16x8_t frag16_tr(const char* tile, int rbase, int b, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int rowA = rbase + 4 * g + (i >> 2), rowB = rowA + 16;
+  const int chunk = 2 * b + ((i & 3) >> 1);
+  const int sub = (i & 1) << 3;
+  u16x4_t lo = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowA, chunk) + sub)));
+  u16x4_t hi = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowB, chunk) + sub)));
+  u16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ bf16x8_t pack2(const f32x4_t& a, const f32x4_t& b) {
+  u16x8_t r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // x <= 0 here; denormal results flush to 0
+
+// physical rows of the two 4-row groups this lane stages for the 64-position tile starting at pos0
+__device__ __forceinline__ void a16_rows(const AttnP& p, int seq0, int seqlen, int pos0, int wave, int lane, int (&pr)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pos = pos0 + (wave * 2 + i) * 4 + (lane >> 4);
+    pr[i] = pos < seqlen ? phys_row(p, seq0 + pos) : 0;
+  }
+}
+// LDS-DMA of one 64-row tile of a [pos][H*HD] operand (8 waves x 2 wave-instructions of 4 rows x 256 B)
+template <int HD>
+__device__ __forceinline__ void a16_stage(__amdgpu_buffer_rsrc_t rs, int ld_b, int head, int seqlen, int pos0, const int (&pr)[2],
+                                          char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = wave * 2 + i;
+    const int row = inst * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ swz16(row);
+    const bool valid = (pos0 + row < seqlen) && (chunk * 8 < HD);
+    const int voff = valid ? pr[i] * ld_b + (head * HD + chunk * 8) * 2 : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(tile + inst * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+#define A16_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// ----------------------------------------------------------------------------- forward (16 queries per wave)
+template <int HD>
+__global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int ND = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int seq0 = p.cu[seq];
+  const int seqlen = p.cu[seq + 1] - seq0;
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= seqlen) return;
+  const int qpos = q0 + wave * 16 + ln;
+  const bool qvalid = qpos < seqlen;
+  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
+
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    i32x4_t v = {0, 0, 0, 0};
+    if (qvalid && 32 * s + 8 * g < HD) v = *reinterpret_cast<const i32x4_t*>(p.q + qrow * p.ldq + head * HD + 32 * s + 8 * g);
+    qf[s] = __builtin_bit_cast(bf16x8_t, v);
+  }
+  f32x4_t o[ND];
+#pragma unroll
+  for (int b = 0; b < ND; ++b) o[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float sc = p.scale * LOG2E;
+
+  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
+  const int nt = (kv_end + 63) / 64;
+  const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
+  const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
+  int pr[2];
+  a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
+  a16_stage<HD>(rK, ldk_b, head, seqlen, 0, pr, smem, wave, lane);
+  a16_stage<HD>(rV, ldv_b, head, seqlen, 0, pr, smem + 64 * ROWB, wave, lane);
+  if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
+  A16_WAIT_ALL();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) {
+      char* nb = smem + (buf ^ 1) * A16_STAGE;
+      a16_stage<HD>(rK, ldk_b, head, seqlen, (t + 1) * 64, pr, nb, wave, lane);
+      a16_stage<HD>(rV, ldv_b, head, seqlen, (t + 1) * 64, pr, nb + 64 * ROWB, wave, lane);
+      if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
+    }
+    const char* sK = smem + buf * A16_STAGE;
+    const char* sV = sK + 64 * ROWB;
+    const int kv0 = t * 64;
+    // S^T sub-tiles: sacc[j][r] = score(kv = kv0 + 16 j + 4 g + r, q = this lane's query)
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sacc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sacc[j], 0, 0, 0);
+    }
+    // masking only on tiles that touch the sequence end or the causal diagonal (wave-uniform test)
+    if (kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16)) {
+      const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[j][r] = (kv0 + 16 * j + 4 * g + r <= lim) ? sacc[j][r] : NEG_BIG;
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[j][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float msc = m_new * sc;
+    const float alpha = fast_exp2(m_run * sc - msc);
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = fast_exp2(__builtin_fmaf(sacc[j][r], sc, -msc));
+        sacc[j][r] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // the running max moved for some query of the wave
+#pragma unroll
+      for (int b = 0; b < ND; ++b) o[b] *= alpha;
+    }
+    // O^T[d][q] += V^T · P^T
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8_t pf = pack2(sacc[2 * c], sacc[2 * c + 1]);
+#pragma unroll
+      for (int b = 0; b < ND; ++b)
+        o[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sV, 32 * c, b, lane), pf, o[b], 0, 0, 0);
+    }
+    A16_WAIT_ALL();
+    __syncthreads();
+  }
+
+  if (!qvalid) return;
+  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (g == 0 && p.lse) p.lse[(int64_t)head * p.total_pos_max + seq0 + qpos] = (m_run * sc + log2f(l_run)) * LN2;
+  unsigned short* orow = p.out + qrow * p.ldo + head * HD;
+#pragma unroll
+  for (int b = 0; b < ND; ++b) {
+    const u16x4_t w = {f2bf(o[b][0] * inv_l), f2bf(o[b][1] * inv_l), f2bf(o[b][2] * inv_l), f2bf(o[b][3] * inv_l)};
+    *reinterpret_cast<u16x4_t*>(orow + 16 * b + 4 * g) = w;
+  }
+}
+
+// ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
+template <int HD>
+__global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int ND = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int seq0 = p.cu[seq];
+  const int seqlen = p.cu[seq + 1] - seq0;
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= seqlen) return;
+  const int qpos = q0 + wave * 16 + ln;
+  const bool qvalid = qpos < seqlen;
+  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
+
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    i32x4_t a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (qvalid && 32 * s + 8 * g < HD) {
+      a = *reinterpret_cast<const i32x4_t*>(p.q + qrow * p.ldq + head * HD + 32 * s + 8 * g);
+      b = *reinterpret_cast<const i32x4_t*>(p.dout + qrow * p.lddo + head * HD + 32 * s + 8 * g);
+    }
+    qf[s] = __builtin_bit_cast(bf16x8_t, a);
+    dof[s] = __builtin_bit_cast(bf16x8_t, b);
+  }
+  // an invalid query gets lse = +inf-like so that its probabilities are exactly zero
+  const float lse2 = qvalid ? p.lse[(int64_t)head * p.total_pos_max + seq0 + qpos] * LOG2E : 1.0e30f;
+  const float dlt = qvalid ? p.delta[(int64_t)head * p.total_pos_max + seq0 + qpos] : 0.f;
+  const float sc = p.scale * LOG2E;
+  f32x4_t dq[ND];
+#pragma unroll
+  for (int b = 0; b < ND; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
+  const int nt = (kv_end + 63) / 64;
+  const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
+  const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
+  int pr[2];
+  a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
+  a16_stage<HD>(rK, ldk_b, head, seqlen, 0, pr, smem, wave, lane);
+  a16_stage<HD>(rV, ldv_b, head, seqlen, 0, pr, smem + 64 * ROWB, wave, lane);
+  if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
+  A16_WAIT_ALL();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) {
+      char* nb = smem + (buf ^ 1) * A16_STAGE;
+      a16_stage<HD>(rK, ldk_b, head, seqlen, (t + 1) * 64, pr, nb, wave, lane);
+      a16_stage<HD>(rV, ldv_b, head, seqlen, (t + 1) * 64, pr, nb + 64 * ROWB, wave, lane);
+      if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
+    }
+    const char* sK = smem + buf * A16_STAGE;
+    const char* sV = sK + 64 * ROWB;
+    const int kv0 = t * 64;
+    f32x4_t sa[4], dp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sa[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sa[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sa[j], 0, 0, 0);
+        dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sV, 16 * j, s, lane), dof[s], dp[j], 0, 0, 0);
+      }
+    }
+    // dS^T = P ∘ (dP^T − delta)   (the softmax scale is applied once, on dQ)
+    const bool edge = kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16);
+    const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pr_ = fast_exp2(__builtin_fmaf(sa[j][r], sc, -lse2));
+        if (edge) pr_ = (kv0 + 16 * j + 4 * g + r <= lim) ? pr_ : 0.f;
+        sa[j][r] = pr_ * (dp[j][r] - dlt);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bf16x8_t df = pack2(sa[2 * c], sa[2 * c + 1]);
+#pragma unroll
+      for (int b = 0; b < ND; ++b)
+        dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sK, 32 * c, b, lane), df, dq[b], 0, 0, 0);
+    }
+    A16_WAIT_ALL();
+    __syncthreads();
+  }
+  if (!qvalid) return;
+  unsigned short* drow = p.dq + qrow * p.lddq + head * HD;
+#pragma unroll
+  for (int b = 0; b < ND; ++b) {
+    const u16x4_t w = {f2bf(dq[b][0] * p.scale), f2bf(dq[b][1] * p.scale), f2bf(dq[b][2] * p.scale), f2bf(dq[b][3] * p.scale)};
+    *reinterpret_cast<u16x4_t*>(drow + 16 * b + 4 * g) = w;
+  }
+}
+
+// ----------------------------------------------------------------------------- backward: dK, dV (16 keys per wave)
+template <int HD>
+__global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
+  constexpr int KS = (HD + 31) / 32;
+  constexpr int ND = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stats = reinterpret_cast<float*>(smem + A16_LDS);     // [stage][lse | delta][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int seq0 = p.cu[seq];
+  const int seqlen = p.cu[seq + 1] - seq0;
+  const int k0 = blockIdx.x * 128;
+  if (k0 >= seqlen) return;
+  const int kpos = k0 + wave * 16 + ln;
+  const bool kvalid = kpos < seqlen;
+  const int64_t krow = kvalid ? phys_row(p, seq0 + kpos) : 0;
+
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    i32x4_t a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (kvalid && 32 * s + 8 * g < HD) {
+      a = *reinterpret_cast<const i32x4_t*>(p.k + krow * p.ldk + head * HD + 32 * s + 8 * g);
+      b = *reinterpret_cast<const i32x4_t*>(p.v + krow * p.ldv + head * HD + 32 * s + 8 * g);
+    }
+    kf[s] = __builtin_bit_cast(bf16x8_t, a);
+    vf[s] = __builtin_bit_cast(bf16x8_t, b);
+  }
+  const float sc = p.scale * LOG2E;
+  f32x4_t dk[ND], dv[ND];
+#pragma unroll
+  for (int b = 0; b < ND; ++b) { dk[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+  const int q_begin = p.causal ? (k0 / 64) * 64 : 0;     // queries before the key block see none of it
+  const int nt = (seqlen - q_begin + 63) / 64;
+  const __amdgpu_buffer_rsrc_t rQ = whole_rsrc(p.q), rDO = whole_rsrc(p.dout);
+  const __amdgpu_buffer_rsrc_t rL = whole_rsrc(p.lse), rD = whole_rsrc(p.delta);
+  const int ldq_b = (int)p.ldq * 2, lddo_b = (int)p.lddo * 2;
+  const int stat_base = (head * p.total_pos_max + seq0) * 4;
+  auto stage_stats = [&](int qq0, int buf) {               // waves 0 / 1: 64 lse / delta values, zero past the sequence
+    if (wave < 2) {
+      const int qp = qq0 + lane;
+      const int voff = qp < seqlen ? stat_base + qp * 4 : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rL : rD, (lds_vptr_t)(stats + buf * 128 + wave * 64), 4, voff, 0, 0, 0);
+    }
+  };
+  int pr[2];
+  a16_rows(p, seq0, seqlen, q_begin, wave, lane, pr);
+  a16_stage<HD>(rQ, ldq_b, head, seqlen, q_begin, pr, smem, wave, lane);
+  a16_stage<HD>(rDO, lddo_b, head, seqlen, q_begin, pr, smem + 64 * ROWB, wave, lane);
+  stage_stats(q_begin, 0);
+  if (nt > 1) a16_rows(p, seq0, seqlen, q_begin + 64, wave, lane, pr);
+  A16_WAIT_ALL();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int qq0 = q_begin + t * 64;
+    if (t + 1 < nt) {
+      char* nb = smem + (buf ^ 1) * A16_STAGE;
+      a16_stage<HD>(rQ, ldq_b, head, seqlen, qq0 + 64, pr, nb, wave, lane);
+      a16_stage<HD>(rDO, lddo_b, head, seqlen, qq0 + 64, pr, nb + 64 * ROWB, wave, lane);
+      stage_stats(qq0 + 64, buf ^ 1);
+      if (t + 2 < nt) a16_rows(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
+    }
+    const char* sQ = smem + buf * A16_STAGE;
+    const char* sDO = sQ + 64 * ROWB;
+    const float* sL = stats + buf * 128;
+    const float* sD = sL + 64;
+    const bool edge = qq0 + 64 > seqlen || (p.causal && qq0 < k0 + 128);
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      // S[q][key], dP[q][key] for 32 queries: lane (key = ln, g) holds q = qq0 + 32 hq + 16 jj + 4 g + r
+      f32x4_t sa[2], dp[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        sa[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dp[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sQ, 32 * hq + 16 * jj, s, lane), kf[s], sa[jj], 0, 0, 0);
+          dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sDO, 32 * hq + 16 * jj, s, lane), vf[s], dp[jj], 0, 0, 0);
+        }
+      }
+      f32x4_t pa[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + 32 * hq + 16 * jj + 4 * g);
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sD + 32 * hq + 16 * jj + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr_ = fast_exp2(__builtin_fmaf(sa[jj][r], sc, -l4[r] * LOG2E));
+          if (edge) {
+            const int qp = qq0 + 32 * hq + 16 * jj + 4 * g + r;
+            pr_ = (qp < seqlen && (!p.causal || kpos <= qp)) ? pr_ : 0.f;
+          }
+          pa[jj][r] = pr_;
+          sa[jj][r] = pr_ * (dp[jj][r] - d4[r]);
+        }
+      }
+      const bf16x8_t pf = pack2(pa[0], pa[1]);
+      const bf16x8_t df = pack2(sa[0], sa[1]);
+#pragma unroll
+      for (int b = 0; b < ND; ++b) {
+        dv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sDO, 32 * hq, b, lane), pf, dv[b], 0, 0, 0);
+        dk[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sQ, 32 * hq, b, lane), df, dk[b], 0, 0, 0);
+      }
+    }
+    A16_WAIT_ALL();
+    __syncthreads();
+  }
+  if (!kvalid) return;
+  unsigned short* dkrow = p.dk + krow * p.lddk + head * HD;
+  unsigned short* dvrow = p.dv + krow * p.lddv + head * HD;
+#pragma unroll
+  for (int b = 0; b < ND; ++b) {
+    const u16x4_t wk = {f2bf(dk[b][0] * p.scale), f2bf(dk[b][1] * p.scale), f2bf(dk[b][2] * p.scale), f2bf(dk[b][3] * p.scale)};
+    const u16x4_t wv = {f2bf(dv[b][0]), f2bf(dv[b][1]), f2bf(dv[b][2]), f2bf(dv[b][3])};
+    *reinterpret_cast<u16x4_t*>(dkrow + 16 * b + 4 * g) = wk;
+    *reinterpret_cast<u16x4_t*>(dvrow + 16 * b + 4 * g) = wv;
+  }
+}
+
 AttnP to_params(const vm_attn_args* a) {
   AttnP p;
   p.q = (const unsigned short*)a->q; p.k = (const unsigned short*)a->k; p.v = (const unsigned short*)a->v;
@@ -479,6 +906,23 @@ bool args_ok(const vm_attn_args* a) {
   if (a->n_seq <= 0 || a->n_heads <= 0 || a->max_seqlen <= 0 || a->total_pos_max <= 0) return false;
   if (a->ldq % 8 || a->ldk % 8 || a->ldv % 8 || a->ldo % 4) return false;
   return true;
+}
+
+// VM_ATTN_IMPL=32 selects the 32-wide kernels (A/B measurements); default: 16-wide
+int attn_impl() {
+  static int impl = -1;
+  if (impl < 0) { const char* e = getenv("VM_ATTN_IMPL"); impl = (e && atoi(e) == 32) ? 32 : 16; }
+  return impl;
+}
+// dynamic LDS above 64 KiB needs the attribute once per kernel
+bool lds_ok(const void* fn, int bytes) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+}
+// the LDS-DMA staging addresses operands with 32-bit byte offsets from the tensor base
+bool fits32(const vm_attn_args* a) {
+  const int64_t rows = 2 * (int64_t)a->total_pos_max;     // physical rows of the packed layout: positions + slack
+  return rows * a->ldq * 2 < OOB_OFF && rows * a->ldk * 2 < OOB_OFF && rows * a->ldv * 2 < OOB_OFF &&
+         (!a->dout || rows * a->lddo * 2 < OOB_OFF) && (int64_t)a->n_heads * a->total_pos_max * 4 < OOB_OFF;
 }
 
 double attn_flops(const vm_attn_args* a, double mult) {
@@ -505,11 +949,18 @@ extern "C" {
 
 int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   if (!args_ok(a)) return VM_ERR_BAD_ARG;
+  if (!fits32(a)) return VM_ERR_UNSUPPORTED;
   AttnP p = to_params(a);
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  ATTN_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  if (attn_impl() == 32) {
+    ATTN_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  } else {
+    ATTN_DISPATCH_HD(a->head_dim,
+                     if (!lds_ok((const void*)attn16_fwd_k<HD>, A16_LDS)) return VM_ERR_LAUNCH;
+                     hipLaunchKernelGGL(attn16_fwd_k<HD>, grid, dim3(512), A16_LDS, (hipStream_t)stream, p));
+  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
   VM_LAUNCH_CHECK();
   return VM_OK;
@@ -518,16 +969,26 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
 int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   if (!args_ok(a) || !a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return VM_ERR_BAD_ARG;
   if (a->lddo % 8 || a->ldo % 8 || a->lddq % 4 || a->lddk % 4 || a->lddv % 4) return VM_ERR_BAD_ARG;
+  if (!fits32(a)) return VM_ERR_UNSUPPORTED;
   AttnP p = to_params(a);
   const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  ATTN_DISPATCH_HD(a->head_dim,
-                   hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                                      (hipStream_t)stream, p, a->n_seq);
-                   hipLaunchKernelGGL(attn_bwd_dq_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p);
-                   hipLaunchKernelGGL(attn_bwd_dkv_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  if (attn_impl() == 32) {
+    ATTN_DISPATCH_HD(a->head_dim,
+                     hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                                        (hipStream_t)stream, p, a->n_seq);
+                     hipLaunchKernelGGL(attn_bwd_dq_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p);
+                     hipLaunchKernelGGL(attn_bwd_dkv_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  } else {
+    ATTN_DISPATCH_HD(a->head_dim,
+                     if (!lds_ok((const void*)attn16_dq_k<HD>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
+                     hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                                        (hipStream_t)stream, p, a->n_seq);
+                     hipLaunchKernelGGL(attn16_dq_k<HD>, grid, dim3(512), A16_LDS, (hipStream_t)stream, p);
+                     hipLaunchKernelGGL(attn16_dkv_k<HD>, grid, dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
+  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
   VM_LAUNCH_CHECK();
   return VM_OK;

@@ -392,7 +392,7 @@ def _attn_ref(q, k, v, cu, scale, causal):
     return out
 
 
-@pytest.mark.parametrize('hd,H,causal', [(128, 2, True), (112, 3, False), (128, 1, False), (64, 2, True)])
+@pytest.mark.parametrize('hd,H,causal', [(128, 2, True), (112, 3, False), (128, 1, False), (64, 2, True), (96, 1, True), (32, 2, False), (16, 1, True)])
 @pytest.mark.parametrize('lens', [[130], [64, 1, 200], [456, 456], [785]])
 def test_attention_bf16(dev, K, hd, H, causal, lens):
     cu = [0]
@@ -430,6 +430,14 @@ def test_attention_bf16_row_indirection(dev, K):
     o_seq, _ = K.attn_fwd(*sl(qkv_seq), cu_t, 90, H, hd, hd ** -0.5, True)
     o_phys, _ = K.attn_fwd(*sl(qkv_phys), cu_t, 90, H, hd, hd ** -0.5, True, row_of_pos=perm.int())
     assert torch.equal(o_phys[perm], o_seq)
+    # the backward follows the same indirection for q/k/v/out/dout rows and for the rows it writes
+    _, lse = K.attn_fwd(*sl(qkv_seq), cu_t, 90, H, hd, hd ** -0.5, True)
+    do_seq = torch.randn(rows, H * hd, device=dev).bfloat16()
+    do_phys = torch.empty_like(do_seq)
+    do_phys[perm] = do_seq
+    g_seq = K.attn_bwd(*sl(qkv_seq), o_seq, lse, do_seq, cu_t, 90, H, hd, hd ** -0.5, True)
+    g_phys = K.attn_bwd(*sl(qkv_phys), o_phys, lse, do_phys, cu_t, 90, H, hd, hd ** -0.5, True, row_of_pos=perm.int())
+    assert torch.equal(g_phys[perm], g_seq)
 
 
 def test_attention_rare_rescale_branch(dev, K):
