@@ -39,6 +39,7 @@ struct AttnP {
   float* lse;
   const int32_t* cu; const int32_t* row_of_pos;
   int total_pos_max, n_heads;
+  int n_seq, n_tiles;      // 16-wide kernels: sequences, 128-position tiles per sequence (1-D XCD-aware grid)
   float scale; int causal;
   const unsigned short* dout; int64_t lddo;
   unsigned short* dq; unsigned short* dk; unsigned short* dv; int64_t lddq, lddk, lddv;
@@ -503,10 +504,9 @@ __device__ __forceinline__ bf16x8_t frag16_tr(const char* tile, int rbase, int b
   const int rowA = rbase + 4 * g + (i >> 2), rowB = rowA + 16;
   const int chunk = 2 * b + ((i & 3) >> 1);
   const int sub = (i & 1) << 3;
-  u16x4_t lo = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowA, chunk) + sub)));
-  u16x4_t hi = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowB, chunk) + sub)));
-  u16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, r);
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowA, chunk) + sub));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowB, chunk) + sub));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ bf16x8_t pack2(const f32x4_t& a, const f32x4_t& b) {
   u16x8_t r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
@@ -522,22 +522,47 @@ __device__ __forceinline__ void a16_rows(const AttnP& p, int seq0, int seqlen, i
     pr[i] = pos < seqlen ? phys_row(p, seq0 + pos) : 0;
   }
 }
-// LDS-DMA of one 64-row tile of a [pos][H*HD] operand (8 waves x 2 wave-instructions of 4 rows x 256 B)
-template <int HD>
-__device__ __forceinline__ void a16_stage(__amdgpu_buffer_rsrc_t rs, int ld_b, int head, int seqlen, int pos0, const int (&pr)[2],
-                                          char* tile, int wave, int lane) {
+// LDS-DMA of one 64-row tile of a [pos][H*HD] operand (8 waves x 2 wave-instructions of 4 rows x 256 B).
+// The lane's tile row and source column are loop invariants (StageLane); per tile only the row's physical index changes.
+struct StageLane {
+  int row[2];    // tile row of wave-instruction i
+  int col[2];    // byte offset of the lane's source chunk inside a row of the operand, or -1 past the head dimension
+  template <int HD>
+  __device__ __forceinline__ void init(int head, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      row[i] = (wave * 2 + i) * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ swz16(row[i]);
+      col[i] = chunk * 8 < HD ? (head * HD + chunk * 8) * 2 : -1;
+    }
+  }
+};
+__device__ __forceinline__ void a16_stage(__amdgpu_buffer_rsrc_t rs, int ld_b, const StageLane& sl, int rows_left, const int (&pr)[2],
+                                          char* tile, int wave) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int inst = wave * 2 + i;
-    const int row = inst * 4 + (lane >> 4);
-    const int chunk = (lane & 15) ^ swz16(row);
-    const bool valid = (pos0 + row < seqlen) && (chunk * 8 < HD);
-    const int voff = valid ? pr[i] * ld_b + (head * HD + chunk * 8) * 2 : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(tile + inst * 1024), 16, voff, 0, 0, 0);
+    const bool valid = sl.row[i] < rows_left && sl.col[i] >= 0;
+    const int voff = valid ? (int)__umul24(pr[i], ld_b) + sl.col[i] : OOB_OFF;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(tile + (wave * 2 + i) * 1024), 16, voff, 0, 0, 0);
   }
 }
 
 #define A16_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// 1-D grid -> (tile, head, sequence). Workgroups b and b + 8 run on the same XCD (one L2 each), so all tiles of one
+// (head, sequence) pair — which stream the same K/V (or Q/dO) rows — are given ids of one residue mod 8 and adjacent
+// slots: the pair's operands are fetched into that XCD's L2 once instead of once per tile. (With the plain 3-D grid the
+// 7 query tiles of a ViT head land on 7 different XCDs and the kernel is bound by the resulting 7x operand traffic.)
+__device__ __forceinline__ bool a16_block(const AttnP& p, int& tile, int& head, int& seq) {
+  const int id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  tile = slot % p.n_tiles;
+  const int hs = (slot / p.n_tiles) * 8 + xcd;
+  if (hs >= p.n_heads * p.n_seq) return false;
+  head = hs % p.n_heads;
+  seq = hs / p.n_heads;
+  return true;
+}
 
 // ----------------------------------------------------------------------------- forward (16 queries per wave)
 template <int HD>
@@ -548,10 +573,11 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  int tile_, head, seq;
+  if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = blockIdx.x * 128;
+  const int q0 = tile_ * 128;
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
@@ -574,10 +600,12 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
   const int nt = (kv_end + 63) / 64;
   const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
   const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
+  StageLane sl;
+  sl.init<HD>(head, wave, lane);
   int pr[2];
   a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
-  a16_stage<HD>(rK, ldk_b, head, seqlen, 0, pr, smem, wave, lane);
-  a16_stage<HD>(rV, ldv_b, head, seqlen, 0, pr, smem + 64 * ROWB, wave, lane);
+  a16_stage(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
+  a16_stage(rV, ldv_b, sl, seqlen - (0), pr, smem + 64 * ROWB, wave);
   if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
   A16_WAIT_ALL();
   __syncthreads();
@@ -586,8 +614,8 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
     const int buf = t & 1;
     if (t + 1 < nt) {
       char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage<HD>(rK, ldk_b, head, seqlen, (t + 1) * 64, pr, nb, wave, lane);
-      a16_stage<HD>(rV, ldv_b, head, seqlen, (t + 1) * 64, pr, nb + 64 * ROWB, wave, lane);
+      a16_stage(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
+      a16_stage(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, nb + 64 * ROWB, wave);
       if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
     }
     const char* sK = smem + buf * A16_STAGE;
@@ -597,9 +625,9 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
     f32x4_t sacc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sacc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, 0, lane), qf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+      for (int s = 1; s < KS; ++s)
         sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sacc[j], 0, 0, 0);
     }
     // masking only on tiles that touch the sequence end or the causal diagonal (wave-uniform test)
@@ -633,10 +661,8 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
     m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // the running max moved for some query of the wave
 #pragma unroll
-      for (int b = 0; b < ND; ++b) o[b] *= alpha;
-    }
+    for (int b = 0; b < ND; ++b) o[b] *= alpha;            // (a wave-uniform "max unchanged" branch costs more in copies)
     // O^T[d][q] += V^T · P^T
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -669,10 +695,11 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  int tile_, head, seq;
+  if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = blockIdx.x * 128;
+  const int q0 = tile_ * 128;
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
@@ -701,10 +728,12 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
   const int nt = (kv_end + 63) / 64;
   const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
   const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
+  StageLane sl;
+  sl.init<HD>(head, wave, lane);
   int pr[2];
   a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
-  a16_stage<HD>(rK, ldk_b, head, seqlen, 0, pr, smem, wave, lane);
-  a16_stage<HD>(rV, ldv_b, head, seqlen, 0, pr, smem + 64 * ROWB, wave, lane);
+  a16_stage(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
+  a16_stage(rV, ldv_b, sl, seqlen - (0), pr, smem + 64 * ROWB, wave);
   if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
   A16_WAIT_ALL();
   __syncthreads();
@@ -713,8 +742,8 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
     const int buf = t & 1;
     if (t + 1 < nt) {
       char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage<HD>(rK, ldk_b, head, seqlen, (t + 1) * 64, pr, nb, wave, lane);
-      a16_stage<HD>(rV, ldv_b, head, seqlen, (t + 1) * 64, pr, nb + 64 * ROWB, wave, lane);
+      a16_stage(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
+      a16_stage(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, nb + 64 * ROWB, wave);
       if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
     }
     const char* sK = smem + buf * A16_STAGE;
@@ -723,10 +752,10 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
     f32x4_t sa[4], dp[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sa[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      dp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      sa[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, 0, lane), qf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sV, 16 * j, 0, lane), dof[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int s = 1; s < KS; ++s) {
         sa[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sa[j], 0, 0, 0);
         dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sV, 16 * j, s, lane), dof[s], dp[j], 0, 0, 0);
       }
@@ -771,10 +800,11 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  int tile_, head, seq;
+  if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int k0 = blockIdx.x * 128;
+  const int k0 = tile_ * 128;
   if (k0 >= seqlen) return;
   const int kpos = k0 + wave * 16 + ln;
   const bool kvalid = kpos < seqlen;
@@ -809,10 +839,12 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? rL : rD, (lds_vptr_t)(stats + buf * 128 + wave * 64), 4, voff, 0, 0, 0);
     }
   };
+  StageLane sl;
+  sl.init<HD>(head, wave, lane);
   int pr[2];
   a16_rows(p, seq0, seqlen, q_begin, wave, lane, pr);
-  a16_stage<HD>(rQ, ldq_b, head, seqlen, q_begin, pr, smem, wave, lane);
-  a16_stage<HD>(rDO, lddo_b, head, seqlen, q_begin, pr, smem + 64 * ROWB, wave, lane);
+  a16_stage(rQ, ldq_b, sl, seqlen - (q_begin), pr, smem, wave);
+  a16_stage(rDO, lddo_b, sl, seqlen - (q_begin), pr, smem + 64 * ROWB, wave);
   stage_stats(q_begin, 0);
   if (nt > 1) a16_rows(p, seq0, seqlen, q_begin + 64, wave, lane, pr);
   A16_WAIT_ALL();
@@ -823,8 +855,8 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
     const int qq0 = q_begin + t * 64;
     if (t + 1 < nt) {
       char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage<HD>(rQ, ldq_b, head, seqlen, qq0 + 64, pr, nb, wave, lane);
-      a16_stage<HD>(rDO, lddo_b, head, seqlen, qq0 + 64, pr, nb + 64 * ROWB, wave, lane);
+      a16_stage(rQ, ldq_b, sl, seqlen - (qq0 + 64), pr, nb, wave);
+      a16_stage(rDO, lddo_b, sl, seqlen - (qq0 + 64), pr, nb + 64 * ROWB, wave);
       stage_stats(qq0 + 64, buf ^ 1);
       if (t + 2 < nt) a16_rows(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
     }
@@ -839,10 +871,10 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
       f32x4_t sa[2], dp[2];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        sa[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        dp[jj] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sQ, 32 * hq + 16 * jj, 0, lane), kf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sDO, 32 * hq + 16 * jj, 0, lane), vf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 1; s < KS; ++s) {
           sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sQ, 32 * hq + 16 * jj, s, lane), kf[s], sa[jj], 0, 0, 0);
           dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sDO, 32 * hq + 16 * jj, s, lane), vf[s], dp[jj], 0, 0, 0);
         }
@@ -893,6 +925,7 @@ AttnP to_params(const vm_attn_args* a) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.lse = a->lse; p.cu = a->cu_seqlens; p.row_of_pos = a->row_of_pos;
   p.total_pos_max = a->total_pos_max; p.n_heads = a->n_heads;
+  p.n_seq = a->n_seq; p.n_tiles = (a->max_seqlen + 127) / 128;
   p.scale = a->scale; p.causal = a->causal;
   p.dout = (const unsigned short*)a->dout; p.lddo = a->lddo;
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv;
@@ -923,6 +956,11 @@ bool fits32(const vm_attn_args* a) {
   const int64_t rows = 2 * (int64_t)a->total_pos_max;     // physical rows of the packed layout: positions + slack
   return rows * a->ldq * 2 < OOB_OFF && rows * a->ldk * 2 < OOB_OFF && rows * a->ldv * 2 < OOB_OFF &&
          (!a->dout || rows * a->lddo * 2 < OOB_OFF) && (int64_t)a->n_heads * a->total_pos_max * 4 < OOB_OFF;
+}
+
+dim3 grid16(const vm_attn_args* a) {
+  const int pairs8 = (a->n_heads * a->n_seq + 7) / 8 * 8;
+  return dim3((unsigned)(pairs8 * ((a->max_seqlen + 127) / 128)));
 }
 
 double attn_flops(const vm_attn_args* a, double mult) {
@@ -959,7 +997,7 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   } else {
     ATTN_DISPATCH_HD(a->head_dim,
                      if (!lds_ok((const void*)attn16_fwd_k<HD>, A16_LDS)) return VM_ERR_LAUNCH;
-                     hipLaunchKernelGGL(attn16_fwd_k<HD>, grid, dim3(512), A16_LDS, (hipStream_t)stream, p));
+                     hipLaunchKernelGGL(attn16_fwd_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p));
   }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
   VM_LAUNCH_CHECK();
@@ -986,8 +1024,8 @@ int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
                      if (!lds_ok((const void*)attn16_dq_k<HD>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
                      hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
                                         (hipStream_t)stream, p, a->n_seq);
-                     hipLaunchKernelGGL(attn16_dq_k<HD>, grid, dim3(512), A16_LDS, (hipStream_t)stream, p);
-                     hipLaunchKernelGGL(attn16_dkv_k<HD>, grid, dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
+                     hipLaunchKernelGGL(attn16_dq_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p);
+                     hipLaunchKernelGGL(attn16_dkv_k<HD>, grid16(a), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
   }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
   VM_LAUNCH_CHECK();
