@@ -233,6 +233,20 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 
+/* LoRA factor gradients: row contraction of a wide streamed operand W [M, C] with a rank-64 operand S [M, 64]
+ * (peft lora.Linear backward: dB = s * dy^T t, dA = s * u^T drop(x); functional._Linear.backward).
+ *   transpose_out == 0: out[c][n] (C rows, 64 columns, ldo)   = [accumulate ? out : 0] + alpha * sum_m W[m][c] S[m][n]
+ *   transpose_out == 1: out[n][c] (64 rows, C columns, ldo)   = the same, stored transposed
+ * drop_p > 0 applies the inverted-dropout mask of element (m, c) of an [*, C] tensor to W (same hash as vm_dropout).
+ * Rows: all M, a routed segment (counts_dev + segment as in vm_gemm_tn_bf16) or nrows_dev. Partial sums over row
+ * ranges go through `workspace` (size from vm_tn_skinny_workspace) and are added in a fixed order: deterministic.
+ * C % 8 == 0, ldw % 8 == 0, lds % 8 == 0. out_dtype VM_BF16 or VM_F32. */
+int vm_tn_skinny_workspace(int M, int C, int64_t* bytes_host);
+int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, int64_t ldo, int out_dtype,
+                      int transpose_out, int accumulate, int M, const int32_t* counts_dev, int segment,
+                      const int32_t* nrows_dev, float alpha, float drop_p, uint64_t drop_seed, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* A table of independent small transposes in ONE launch: desc_dev holds n records of six int64
  * {src ptr, dst ptr, rows, cols, ld_src, ld_dst}; dst[c, r] = src[r, c]. Used to refresh the K-contiguous copies of
  * every LoRA factor (peft lora_A/lora_B of scripts/cli.py:82-85) once per optimizer step instead of once per use.

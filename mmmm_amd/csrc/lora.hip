@@ -297,6 +297,165 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
     }
 }
 
+// ============================================================================ vm_tn_skinny (LoRA factor gradients)
+// O[c][n] = sum_m W[m][c] * S[m][n] with a WIDE streamed operand W [M, C] and a rank-64 operand S [M, 64]:
+//   dB[N, 64] = s * dy^T t      (W = dy, S = t)            -> out[c][n]
+//   dA[64, K] = s * u^T drop(x) (W = x with the forward's LoRA dropout mask, S = u) -> out[n][c] (transpose_out)
+// A workgroup owns 64 columns of W and a range of rows; 32-row steps run through a 4-stage LDS-DMA ring (three steps of
+// loads in flight, one barrier per step). Row-range partial sums go to an fp32 workspace and tn_reduce_k adds them in a
+// fixed order, scales, optionally accumulates into the existing gradient and writes bf16 / fp32 (deterministic: no
+// atomics, no pre-zeroed buffer, no separate cast).
+struct SkP {
+  const unsigned short* W; int64_t ldw; int C;
+  const unsigned short* S; int64_t lds;
+  float* ws; int c_pad;
+  int M;
+  const int32_t* counts_dev; int segment;
+  const int32_t* nrows_dev;
+  int splits;
+  float drop_p; uint64_t seed;
+};
+constexpr int SK_STAGE = 2 * 32 * ROWB;
+constexpr int SK_STAGES = 4;
+
+// BC = 64: waves as 2 (c) x 2 (n), one 32x32 accumulator each — many small tiles for narrow W (C of a few thousand);
+// BC = 128: wave w owns columns 32w..32w+31 and both n halves — full 256-byte row segments for wide W.
+template <int BC>
+__global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
+  __shared__ __attribute__((aligned(16))) char smem[SK_STAGES * SK_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NB = BC == 128 ? 2 : 1;                 // 32-wide n blocks per wave
+  const int c0 = blockIdx.x * BC;
+  const int wc = BC == 128 ? wave : wave >> 1, wn = BC == 128 ? 0 : wave & 1;
+  int rb = 0, re = p.M;
+  if (p.counts_dev) {
+    const int k0 = __builtin_amdgcn_readfirstlane(p.counts_dev[0]);
+    const int k1 = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
+    if (p.segment == 0) { rb = 0; re = min(k0, k1); }
+    else if (p.segment == 1) { rb = min(k0, k1); re = k1; }
+    else { rb = 0; re = k1; }
+  } else if (p.nrows_dev) {
+    re = min(p.M, __builtin_amdgcn_readfirstlane(p.nrows_dev[0]));
+  }
+  const int total_steps = (re - rb + 31) / 32;
+  const int per = (total_steps + p.splits - 1) / p.splits;
+  const int s_begin = blockIdx.y * per, s_end = min(total_steps, s_begin + per);
+
+  f32x16_t acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  const int c_end = min(p.C, c0 + BC);         // BC = 64: 128-byte row segments (half of the DMA lanes fetch zeros)
+  auto stage = [&](int step, int buf) {      // steps past the range stage zero rows (uniform DMA count for s_waitcnt)
+    const int r0 = rb + step * 32;
+    const int valid = step < s_end ? min(32, re - r0) : 0;
+    char* sw = smem + buf * SK_STAGE;
+    stage_rows(p.W, p.ldw, r0, valid, c0, c_end, sw, wave, lane);
+    stage_rows(p.S, p.lds, r0, valid, 0, 64, sw + 32 * ROWB, wave, lane);
+  };
+  const bool drop = p.drop_p > 0.f;
+  const unsigned thr = vm_drop_threshold(p.drop_p);
+  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+
+  stage(s_begin, 0); stage(s_begin + 1, 1); stage(s_begin + 2, 2);
+  for (int st = s_begin; st < s_end; ++st) {
+    const int buf = (st - s_begin) & 3;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's part of step `st` has landed (2 steps stay in flight)
+    __syncthreads();                                        // ... everybody's has, and step st-1 has been consumed
+    stage(st + 3, (buf + 3) & 3);
+    char* sw = smem + buf * SK_STAGE;
+    const char* ss = sw + 32 * ROWB;
+    if (drop) {
+      const int r0 = rb + st * 32;
+#pragma unroll
+      for (int i = 0; i < BC / 64; ++i) {       // 32 rows x BC/8 chunks: one (BC = 64) or two 16-byte chunks per thread
+        const int cc = tid + i * 256;
+        const int row = BC == 128 ? cc >> 4 : cc >> 3, chunk = BC == 128 ? cc & 15 : cc & 7;
+        const int col = c0 + chunk * 8;
+        char* addr = sw + tile_off(row, chunk);
+        u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
+        const uint64_t idx = (uint64_t)(r0 + row) * (uint64_t)p.C + (uint64_t)col;
+        const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(v[e]) * inv_keep) : (unsigned short)0;
+        *reinterpret_cast<u16x8_t*>(addr) = v;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t wa = frag_tr(sw, 16 * ks, wc, lane);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, frag_tr(ss, 16 * ks, wn + b, lane), acc[b], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-row tail stages before the LDS is released
+  // partial tile: ws[split][c][n], n fastest
+  const int h = lane >> 5;
+  float* w = p.ws + ((int64_t)blockIdx.y * p.c_pad + c0 + wc * 32) * 64 + 32 * wn + (lane & 31);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * b] = acc[b][r];
+}
+
+// out = (accumulate ? out : 0) + alpha * sum_s ws[s]; block = 16 columns c x 64 n, one float4 of n per thread;
+// the transposed form goes through LDS so that a thread writes 4 consecutive c
+template <typename TO>
+__global__ __launch_bounds__(256) void tn_reduce_k(const float* __restrict__ ws, int c_pad, int C, int splits, TO* __restrict__ out,
+                                                   int64_t ldo, int transpose_out, int accumulate, float alpha) {
+  __shared__ float tile[64][17];
+  const int c0 = blockIdx.x * 16;
+  const int tid = threadIdx.x;
+  const int cl = tid >> 4, n4 = (tid & 15) * 4;
+  const float* src = ws + (int64_t)(c0 + cl) * 64 + n4;
+  const int64_t sstride = (int64_t)c_pad * 64;
+  f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {          // four loads in flight; the summation order stays s = 0, 1, 2, ...
+    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (s + 0) * sstride);
+    const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (s + 1) * sstride);
+    const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (s + 2) * sstride);
+    const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(src + (s + 3) * sstride);
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; s < splits; ++s) a += *reinterpret_cast<const f32x4_t*>(src + s * sstride);
+  a *= alpha;
+  if (!transpose_out) {
+    if (c0 + cl < C) {
+      TO* o = out + (int64_t)(c0 + cl) * ldo + n4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = Elem<TO>::st(a[e] + (accumulate ? Elem<TO>::ld(o[e]) : 0.f));
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) tile[n4 + e][cl] = a[e];
+  __syncthreads();
+  const int n = tid >> 2, cb = (tid & 3) * 4;      // thread -> row n, 4 consecutive c
+  TO* o = out + (int64_t)n * ldo + c0 + cb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c0 + cb + e < C) o[e] = Elem<TO>::st(tile[n][cb + e] + (accumulate ? Elem<TO>::ld(o[e]) : 0.f));
+}
+
+// row splits: about 1.5 workgroups per CU, at least 8 steps each; the fp32 partials then stay a fraction of the input
+static int tn_skinny_bc(int C) { return C >= 6144 ? 128 : 64; }
+static int tn_skinny_splits(int M, int C) {
+  const int bc = tn_skinny_bc(C);
+  const int tiles = (C + bc - 1) / bc;
+  const int steps = (M + 31) / 32;
+  int want = (384 + tiles - 1) / tiles;
+  want = max(1, min(want, steps / 8));
+  const int per = (steps + want - 1) / want;
+  return (steps + per - 1) / per;
+}
+
 }  // namespace
 
 extern "C" {
@@ -373,6 +532,49 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
   hipLaunchKernelGGL(gemm_tn_k, dim3(p.tiles_p * p.tiles_q, splits), dim3(256), 0, (hipStream_t)stream, p);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * (double)M * P * Q);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_tn_skinny_workspace(int M, int C, int64_t* bytes_host) {
+  if (!bytes_host || M <= 0 || C <= 0) return VM_ERR_BAD_ARG;
+  const int c_pad = (C + 127) / 128 * 128;
+  *bytes_host = (int64_t)tn_skinny_splits(M, C) * c_pad * 64 * 4;
+  return VM_OK;
+}
+
+int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, int64_t ldo, int out_dtype,
+                      int transpose_out, int accumulate, int M, const int32_t* counts_dev, int segment,
+                      const int32_t* nrows_dev, float alpha, float drop_p, uint64_t drop_seed, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  if (!W || !S || !out || !workspace) return VM_ERR_BAD_ARG;
+  if (C <= 0 || M <= 0) return VM_OK;
+  if (ldw % 8 || lds % 8 || C % 8) return VM_ERR_BAD_ARG;
+  if (out_dtype != VM_BF16 && out_dtype != VM_F32) return VM_ERR_BAD_ARG;
+  if ((int64_t)32 * ldw * 2 + 256 >= (1ll << 31) || (int64_t)32 * lds * 2 + 256 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
+  SkP p;
+  p.W = (const unsigned short*)W; p.ldw = ldw; p.C = C;
+  p.S = (const unsigned short*)S; p.lds = lds;
+  p.M = M;
+  p.counts_dev = counts_dev; p.segment = counts_dev ? segment : -1;
+  p.nrows_dev = nrows_dev;
+  p.splits = tn_skinny_splits(M, C);
+  p.c_pad = (C + 127) / 128 * 128;
+  if (workspace_bytes < (int64_t)p.splits * p.c_pad * 64 * 4) return VM_ERR_BAD_ARG;
+  p.ws = (float*)workspace;
+  p.drop_p = drop_p; p.seed = drop_seed;
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_LORA, stream, &tok);
+  if (tn_skinny_bc(C) == 128) hipLaunchKernelGGL(tn_skinny_k<128>, dim3(p.c_pad / 128, p.splits), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(tn_skinny_k<64>, dim3(p.c_pad / 64, p.splits), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 rg(p.c_pad / 16);
+  if (out_dtype == VM_BF16)
+    hipLaunchKernelGGL(tn_reduce_k<unsigned short>, rg, dim3(256), 0, (hipStream_t)stream, (const float*)p.ws, p.c_pad, C, p.splits,
+                       (unsigned short*)out, ldo, transpose_out, accumulate, alpha);
+  else
+    hipLaunchKernelGGL(tn_reduce_k<float>, rg, dim3(256), 0, (hipStream_t)stream, (const float*)p.ws, p.c_pad, C, p.splits,
+                       (float*)out, ldo, transpose_out, accumulate, alpha);
+  vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * (double)M * C * 64.0);
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -43,6 +43,10 @@ class BucketedGradAllReduce:
         self._next = 0
         self._build(bucket_bytes)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # fused weight-gradient kernels (functional._lora_wgrad) accumulate straight into the bucket view `p.grad` and
+        # bypass AccumulateGrad; they report the slot through this callback instead of the hook above
+        for p in self.params:
+            p._vm_grad_ready = self._on_grad
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):
@@ -141,5 +145,8 @@ class BucketedGradAllReduce:
         return total
 
     def remove(self):
+        for p in self.params:
+            if getattr(p, '_vm_grad_ready', None) is not None:
+                del p._vm_grad_ready
         for h in self._hooks:
             h.remove()

@@ -63,6 +63,24 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
     return K.gemm(xdp, A0p, w1=A1p if gated else None, counts=counts if gated else None)
 
 
+def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
+    """gradient of one LoRA factor through the skinny row-contraction kernel. When the parameter's gradient lives in a
+    flat reduction bucket (ddp.BucketedGradAllReduce tags it with `_vm_grad_ready`) the kernel accumulates straight into
+    that view and autograd gets None: no temporary, no AccumulateGrad add, and the bucket is told the slot is ready."""
+    if not K.tn_skinny_supported(W, S):
+        if transpose_out:
+            return K.gemm_tn(S, W, counts=counts, segment=seg, alpha=scale, drop_p=drop_p, drop_seed=seed)
+        return K.gemm_tn(W, S, counts=counts, segment=seg, alpha=scale)
+    ready = getattr(param, '_vm_grad_ready', None)
+    if ready is not None and param.grad is not None and param.grad.dtype in (torch.bfloat16, torch.float32):
+        K.tn_skinny(W, S, transpose_out=transpose_out, out=param.grad, accumulate=True, counts=counts, segment=seg, alpha=scale,
+                    drop_p=drop_p, drop_seed=seed)
+        ready(param)
+        return None
+    return K.tn_skinny(W, S, transpose_out=transpose_out, counts=counts, segment=seg, alpha=scale, drop_p=drop_p, drop_seed=seed,
+                       out_dtype=param.dtype)
+
+
 class _Linear(Function):
     """y = act(x W^T + s·(drop(x) A^T) B^T + b) + residual, optionally per row segment.
 
@@ -125,10 +143,10 @@ class _Linear(Function):
                 # row-contraction MFMA kernel on the row-major activations as they are: no transposed copies
                 if need[base]:
                     g[base] = K.gemm_tn(dy, x, counts=cnt, segment=seg)
-                if lora and need[base + 4]:                                   # dB = s · dy^T · t
-                    g[base + 4] = K.gemm_tn(dy, t, counts=cnt, segment=seg, alpha=s)
-                if lora and need[base + 3]:                                   # dA = s · u^T · drop(x)
-                    g[base + 3] = K.gemm_tn(u, x, counts=cnt, segment=seg, alpha=s, drop_p=meta.drop_p, drop_seed=meta.drop_seed)
+                if lora and need[base + 4]:                                   # dB [N, r] = s · dy^T · t
+                    g[base + 4] = _lora_wgrad(B, dy, t, False, cnt, seg, s, 0.0, 0)
+                if lora and need[base + 3]:                                   # dA [r, K] = s · u^T · drop(x)
+                    g[base + 3] = _lora_wgrad(A, x, u, True, cnt, seg, s, meta.drop_p, meta.drop_seed)
             else:
                 # fp32 islands / odd shapes: K-contiguous transposes feed the NT kernel
                 def tr(z):

@@ -180,6 +180,36 @@ def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = N
 VM_F32_ = hip.VM_F32
 
 
+@functools.lru_cache(maxsize=256)
+def _tn_skinny_ws_bytes(M: int, Cw: int) -> int:
+    n = C.c_int64(0)
+    hip.call('vm_tn_skinny_workspace', M, Cw, C.addressof(n))
+    return n.value
+
+
+def tn_skinny_supported(W: torch.Tensor, S: torch.Tensor) -> bool:
+    return (W.dtype == torch.bfloat16 and S.dtype == torch.bfloat16 and S.shape[1] == 64 and W.shape[1] % 8 == 0
+            and W.stride(1) == 1 and S.stride(1) == 1 and W.stride(0) % 8 == 0 and S.stride(0) % 8 == 0)
+
+
+def tn_skinny(W: torch.Tensor, S: torch.Tensor, *, transpose_out: bool, out: torch.Tensor | None = None, accumulate: bool = False,
+              counts: torch.Tensor | None = None, segment: int = -1, nrows: torch.Tensor | None = None, alpha: float = 1.0,
+              drop_p: float = 0.0, drop_seed: int = 0, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+    """LoRA factor gradient: out[c][n] (or out[n][c] when transpose_out) (+)= alpha * sum_m drop(W)[m][c] * S[m][n].
+    W [M, C] is the wide streamed operand, S [M, 64]; deterministic (workspace partials reduced in a fixed order)."""
+    M, Cw = W.shape
+    assert S.shape == (M, 64)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((64, Cw) if transpose_out else (Cw, 64), dtype=out_dtype or W.dtype, device=W.device)
+    assert out.shape == ((64, Cw) if transpose_out else (Cw, 64)) and out.stride(1) == 1
+    nbytes = _tn_skinny_ws_bytes(M, Cw)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=W.device)
+    hip.call('vm_tn_skinny_bf16', ptr(W), _ld(W), Cw, ptr(S), _ld(S), ptr(out), _ld(out), dtype_code(out.dtype), int(transpose_out),
+             int(accumulate), M, ptr(counts), segment, ptr(nrows), alpha, drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, ptr(ws), nbytes, stream())
+    return out
+
+
 # ------------------------------------------------------------------ norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tensor | None = None):
     x = _c(x)

@@ -495,6 +495,44 @@ def test_gemm_tn(dev, K, M, P, Q):
     assert rel_err(out2, 0.5 * ref) < 3e-3 if True else None
 
 
+@pytest.mark.parametrize('M,Cw', [(6280, 1792), (3648, 4096), (517, 200), (40, 64), (6280, 15360)])
+def test_tn_skinny(dev, K, M, Cw):
+    """LoRA factor gradients: out[c][n] / out[n][c] = alpha * W^T S, deterministic, optional accumulate and dropout"""
+    W = torch.randn(M, Cw, device=dev).bfloat16()
+    S = torch.randn(M, 64, device=dev).bfloat16()
+    ref = W.float().T @ S.float()
+    a = K.tn_skinny(W, S, transpose_out=False, alpha=0.5)
+    assert a.shape == (Cw, 64) and rel_err(a, 0.5 * ref) < 4e-3
+    b = K.tn_skinny(W, S, transpose_out=True, alpha=0.5, out_dtype=torch.float32)
+    assert b.shape == (64, Cw) and b.dtype == torch.float32 and rel_err(b, 0.5 * ref.T) < 1e-5
+    assert torch.equal(a, K.tn_skinny(W, S, transpose_out=False, alpha=0.5))        # fixed summation order
+    base = torch.randn(64, Cw, device=dev).bfloat16()
+    acc = base.clone()
+    K.tn_skinny(W, S, transpose_out=True, out=acc, accumulate=True)
+    assert rel_err(acc, base.float() + ref.T) < 6e-3
+    p, seed = 0.1, 99
+    Wd = K.dropout(W, p, seed)
+    d = K.tn_skinny(W, S, transpose_out=True, drop_p=p, drop_seed=seed, out_dtype=torch.float32)
+    assert rel_err(d, (Wd.float().T @ S.float()).T) < 1e-5
+
+
+def test_tn_skinny_segments(dev, K):
+    M, Cw = 517, 256
+    W = torch.randn(640, Cw, device=dev).bfloat16()
+    S = torch.randn(640, 64, device=dev).bfloat16()
+    counts = torch.tensor([200, M, 0, 0], dtype=torch.int32, device=dev)
+    r0 = W[:200].float().T @ S[:200].float()
+    r1 = W[200:M].float().T @ S[200:M].float()
+    f = torch.float32
+    assert rel_err(K.tn_skinny(W, S, transpose_out=False, counts=counts, segment=0, out_dtype=f), r0) < 1e-5
+    assert rel_err(K.tn_skinny(W, S, transpose_out=False, counts=counts, segment=1, out_dtype=f), r1) < 1e-5
+    assert rel_err(K.tn_skinny(W, S, transpose_out=False, counts=counts, segment=-1, out_dtype=f), r0 + r1) < 1e-5
+    n = torch.tensor([M], dtype=torch.int32, device=dev)
+    assert rel_err(K.tn_skinny(W, S, transpose_out=True, nrows=n, out_dtype=f), (r0 + r1).T) < 1e-5
+    empty = torch.tensor([0, 0, 0, 0], dtype=torch.int32, device=dev)
+    assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
+
+
 def test_gemm_tn_segments_and_dropout(dev, K):
     M, P, Q = 517, 64, 256
     X = torch.randn(640, P, device=dev).bfloat16()

@@ -18,3 +18,8 @@ for M, Kd in [(6280, 15360), (6280, 1792), (6280, 5376), (3648, 4096), (3648, 11
         print(f'gemm_tn [64 x {Kd}] over {M} rows drop={dp}: {ms*1e3:.1f} us  {M*Kd*2/ms/1e9:.2f} TB/s', flush=True)
     ms = timeit(lambda: K.gemm_tn(x, u, alpha=0.5), iters=30)
     print(f'gemm_tn [{Kd} x 64] over {M} rows: {ms*1e3:.1f} us  {M*Kd*2/ms/1e9:.2f} TB/s', flush=True)
+    for dp in (0.0, 0.05):
+        ms = timeit(lambda: K.tn_skinny(x, u, transpose_out=True, alpha=0.5, drop_p=dp, drop_seed=3), iters=30)
+        print(f'tn_skinny dA [64 x {Kd}] over {M} rows drop={dp}: {ms*1e3:.1f} us  {M*Kd*2/ms/1e9:.2f} TB/s', flush=True)
+    ms = timeit(lambda: K.tn_skinny(x, u, transpose_out=False, alpha=0.5), iters=30)
+    print(f'tn_skinny dB [{Kd} x 64] over {M} rows: {ms*1e3:.1f} us  {M*Kd*2/ms/1e9:.2f} TB/s', flush=True)
