@@ -95,7 +95,9 @@ def build(workload: dict, device, depth_scale: float = 1.0):
                                         disc_focal_gamma=2, disc_focal_alpha=0.85)
             torch.set_default_dtype(torch.bfloat16)
         model = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(8, 32, 32), pt_pos_embed_shape=(35, 35), patch_size=16),
-                                      tokenizer=tok, sam=sam, mask_loss=mask_loss, isam=isam, isam_loss=isam_loss, config=cfg)
+                                      tokenizer=tok, sam=sam, mask_loss=mask_loss, isam=isam, isam_loss=isam_loss, config=cfg,
+                                      # Stage 1 / Stage 3 command lines of the reference README (:36, :40): --model.freeze_sam false --model.freeze_isam false
+                                      freeze_sam=False, freeze_isam=False)
     torch.set_default_dtype(torch.float32)
     if workload['sam']:
         model.vg_proj.float()
@@ -289,7 +291,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
-                       'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05',
+                       'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
                        'gradient_checkpointing': plan, 'optimizer': 'AdamW(fused) + clip 1.0', 'depth_scale': args.depth_scale},
             'loss': loss_v,
             'model_tflops_per_image': fl_sample / 1e12,
@@ -297,9 +299,17 @@ def main():
         }
         if use_events:
             ms, fl, n = K.prof_collect(hip.PROF_GEMM_BF16)
+            alg_bytes = K.prof_last_bytes() / max(n, 1)
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+            traffic, traffic_src = None, None
+            tf = Path(__file__).resolve().parent / 'profiles' / 'r1_gemm_traffic.json'
+            if tf.exists():          # PMC passes cannot run inside this process: the committed rocprofv3 measurement
+                tj = json.loads(tf.read_text())
+                traffic, traffic_src = tj['bytes_per_launch'], 'profiles/r1_gemm_traffic.json: ' + tj['source']
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
+                               'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_flops_per_launch': fl / max(n, 1),
                                'launches': n, 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * 1e-3 / dt,
                                'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over every launch of the timed region / summed HIP-event durations'}
             ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)

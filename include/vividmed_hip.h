@@ -55,6 +55,8 @@ int vm_device_arch(char* name_host, int len);
 int vm_prof_enable(int kind_mask);   /* bit k set: bracket launches of kind VM_PROF_* == k; 0 disables */
 int vm_prof_reset(void);
 int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, int64_t* launches_host);
+/* algorithmic bytes (operands read once + result written once) summed by the last vm_prof_collect (GEMM kinds) */
+int vm_prof_last_bytes(double* bytes_host);
 #define VM_PROF_GEMM_BF16 0
 #define VM_PROF_GEMM_F32 1
 #define VM_PROF_ATTN 2

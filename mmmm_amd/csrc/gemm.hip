@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------ event profiling
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; double bytes; };
 struct ProfState {
   std::mutex mu;
   unsigned mask = 0;       // bit k: bracket launches of kind k
@@ -262,6 +262,7 @@ struct ProfState {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 ProfState& prof() { static ProfState s; return s; }
+double& prof_last_bytes() { static double b = 0; return b; }
 
 }  // namespace
 
@@ -273,18 +274,20 @@ extern "C" int vm_prof_begin_(int kind, void* stream, void** tok) {
   ProfRec r;
   if (!s.pool.empty()) { r.a = s.pool.back().first; r.b = s.pool.back().second; s.pool.pop_back(); }
   else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { *tok = nullptr; return 0; } }
-  r.flops = 0;
+  r.flops = 0; r.bytes = 0;
   (void)hipEventRecord(r.a, (hipStream_t)stream);
   s.recs[kind].push_back(r);
   *tok = (void*)(uintptr_t)(s.recs[kind].size());  // 1-based index
   return 0;
 }
-extern "C" int vm_prof_end_(int kind, void* stream, void* tok, double flops) {
+extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, double bytes);
+extern "C" int vm_prof_end_(int kind, void* stream, void* tok, double flops) { return vm_prof_end2_(kind, stream, tok, flops, 0.0); }
+extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, double bytes) {
   if (!tok) return 0;
   ProfState& s = prof();
   std::lock_guard<std::mutex> lk(s.mu);
   ProfRec& r = s.recs[kind][(size_t)(uintptr_t)tok - 1];
-  r.flops = flops;
+  r.flops = flops; r.bytes = bytes;
   (void)hipEventRecord(r.b, (hipStream_t)stream);
   return 0;
 }
@@ -306,6 +309,10 @@ int vm_device_arch(char* name_host, int len) {
 
 int vm_prof_enable(int kind_mask) { prof().mask = (unsigned)kind_mask & 0xFu; return VM_OK; }
 
+/* algorithmic operand + result bytes (A, B, extension operands read once, C written once) summed by the LAST
+ * vm_prof_collect call (bf16 / fp32 GEMM kinds; 0 for the others) */
+int vm_prof_last_bytes(double* bytes_host) { if (!bytes_host) return VM_ERR_BAD_ARG; *bytes_host = prof_last_bytes(); return VM_OK; }
+
 int vm_prof_reset(void) {
   ProfState& s = prof();
   std::lock_guard<std::mutex> lk(s.mu);
@@ -317,13 +324,14 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
   if (kind < 0 || kind > 3) return VM_ERR_BAD_ARG;
   ProfState& s = prof();
   std::lock_guard<std::mutex> lk(s.mu);
-  double ms = 0, fl = 0;
+  double ms = 0, fl = 0, by = 0;
   for (auto& r : s.recs[kind]) {
     if (hipEventSynchronize(r.b) != hipSuccess) return VM_ERR_LAUNCH;
     float t = 0;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return VM_ERR_LAUNCH;
-    ms += t; fl += r.flops;
+    ms += t; fl += r.flops; by += r.bytes;
   }
+  prof_last_bytes() = by;
   if (total_ms_host) *total_ms_host = ms;
   if (total_flops_host) *total_flops_host = fl;
   if (launches_host) *launches_host = (int64_t)s.recs[kind].size();
@@ -406,7 +414,8 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
     hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL((gemm_nt_k<2, false>), dim3(grid), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
-  vm_prof_end_(kind, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2));
+  vm_prof_end2_(kind, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2),
+                ((double)a->M * (a->K + a->K2) + (double)a->N * (a->K + a->K2)) * esz + (double)a->M * a->N * (a->out_dtype == VM_F32 ? 4 : 2));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -52,9 +52,12 @@ def gemm(
     # tiny M x N with a long contraction (weight gradients of the hyper-network mask products): one tile would walk
     # all of K alone, so K is split over workgroups that accumulate into a zeroed fp32 C
     ksplit = 0
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if (out is None and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
-            and ((M + 127) // 128) * ((N + 127) // 128) <= 8 and K >= 1024):
-        ksplit = min(64, K // (4 * (32 if f32 else 64)))
+            and tiles <= 48 and K >= 1024):
+        # a handful of output tiles with a long contraction (weight gradients of the fp32 grounding heads). Only for small
+        # outputs: the fp32 atomic epilogue runs at ~60 G atomics/s and already costs more than it saves at 150 tiles.
+        ksplit = max(1, min(64, K // (4 * (32 if f32 else 64)), -(-400 // tiles)))
     if out is None:
         al = 8 if out_dtype == torch.bfloat16 else 4
         Np = (N + al - 1) // al * al                 # keep ldc aligned for the vector stores of the epilogue
@@ -450,6 +453,12 @@ def prof_enable(kinds=True):
 
 def prof_reset():
     hip.call('vm_prof_reset')
+
+
+def prof_last_bytes() -> float:
+    b = C.c_double()
+    hip.call('vm_prof_last_bytes', C.addressof(b))
+    return b.value
 
 
 def prof_collect(kind: int):

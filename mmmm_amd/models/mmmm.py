@@ -8,6 +8,8 @@ unchanged (INTEGRATION.md).
 """
 from __future__ import annotations
 
+import contextlib
+
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -122,6 +124,8 @@ class MMMMForCausalLM(CogVLMForCausalLM):
                   isam.mask_decoder.txt_align_upscaled_embedding):
             m.requires_grad_(False)
 
+    concurrent_heads: bool = True      # SAM and iSAM on two HIP streams (visual_grounding)
+
     def get_fp32_children(self) -> list[str]:
         return ['sam', 'isam_model', 'vg_proj']
 
@@ -172,13 +176,29 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         disc_logit: list = [None] * B
         sem = [i for i in range(B) if not instance_mask[i]]
         ins = [i for i in range(B) if instance_mask[i]]
+        # SAM (semantic samples) and iSAM (instance samples) are independent fp32 networks whose linears (M ~ 3k rows)
+        # each fill barely half of the 256 CUs: run them on two HIP streams. Autograd replays every backward node on the
+        # stream of its forward, so the two backward passes overlap as well.
+        side = None
+        if sem and ins and self.concurrent_heads and vg_prompts[0].is_cuda:
+            cur = torch.cuda.current_stream()
+            if getattr(self, '_side_stream', None) is None:
+                object.__setattr__(self, '_side_stream', torch.cuda.Stream(device=vg_prompts[0].device))
+            side = self._side_stream
+            side.wait_stream(cur)
+        if ins:
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                out_i = self.isam_model([image[i] for i in ins], [patch_size[i] for i in ins], [vg_prompts[i] for i in ins])
         if sem:
             out = self.sam([image[i] for i in sem], [patch_size[i] for i in sem], [vg_prompts[i] for i in sem])
             for i, m in zip(sem, out):
                 masks_logits[i] = m
         if ins:
-            out = self.isam_model([image[i] for i in ins], [patch_size[i] for i in ins], [vg_prompts[i] for i in ins])
-            for i, b, d in zip(ins, out.boxes, out.disc_logit):
+            if side is not None:
+                cur.wait_stream(side)
+                for t in (*out_i.boxes, *out_i.disc_logit):
+                    t.record_stream(cur)
+            for i, b, d in zip(ins, out_i.boxes, out_i.disc_logit):
                 boxes[i], disc_logit[i] = b, d
         return masks_logits, boxes, disc_logit
 
