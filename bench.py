@@ -218,8 +218,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the VividMed hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('VM_FORCE_DIST') == '1'      # VM_FORCE_DIST: exercise the RCCL path on one rank
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
@@ -228,7 +231,7 @@ def main():
     w = WORKLOADS[args.workload]
     model, tok = build(w, device, args.depth_scale)
     trainable = [p for p in model.parameters() if p.requires_grad]
-    ddp = BucketedGradAllReduce(trainable, world_size=world)
+    ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist)
     opt = torch.optim.AdamW(trainable, lr=5e-5, weight_decay=0.01, fused=True)
     batch = make_batch(w, tok, args.batch, device, seed=rank)      # resident in HBM before timing
 
@@ -251,7 +254,7 @@ def main():
         torch.cuda.synchronize()
         total_hbm = torch.cuda.get_device_properties(device).total_memory
         budget = int(0.88 * total_hbm) - torch.cuda.max_memory_allocated() - (8 << 30)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([budget], device=device, dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             budget = int(t.item())
@@ -264,19 +267,19 @@ def main():
     if use_events:
         K.prof_reset()
         K.prof_enable(True if args.all_kernel_events else (hip.PROF_GEMM_BF16,))
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     if use_events:
         K.prof_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -321,7 +324,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, model.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

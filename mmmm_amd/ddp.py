@@ -29,15 +29,18 @@ class _Bucket:
     pending: int = 0
     launched: bool = False
     work: object = None
+    streams: set = field(default_factory=set)     # device streams that produced gradients of this bucket in this step
 
 
 class BucketedGradAllReduce:
-    def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None):
+    def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None,
+                 force_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.pg = process_group
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.world_size = world_size
+        self.collectives = world_size > 1 or force_collectives      # force: run the all-reduce even on one rank (tests)
         self.buckets: list[_Bucket] = []
         self._bucket_of: dict[int, int] = {}
         self._next = 0
@@ -87,10 +90,18 @@ class BucketedGradAllReduce:
     def _on_grad(self, p: torch.Tensor):
         b = self.buckets[self._bucket_of[id(p)]]
         b.pending -= 1
+        if p.is_cuda:       # backward nodes run on the stream of their forward (the grounding heads use a side stream)
+            b.streams.add(torch.cuda.current_stream(p.device))
         self._launch_ready()
 
     def _launch(self, b: _Bucket):
-        if self.world_size > 1:
+        if b.streams:       # the launching stream must see every producer stream's gradient writes
+            cur = torch.cuda.current_stream(b.buffer.device)
+            for st in b.streams:
+                if st != cur:
+                    cur.wait_stream(st)
+            b.streams.clear()
+        if self.collectives:
             b.buffer.div_(self.world_size)
             b.work = dist.all_reduce(b.buffer, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         b.launched = True
