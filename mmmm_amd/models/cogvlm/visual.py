@@ -24,15 +24,44 @@ class ParameterWrapper(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(weight)
 
+    @classmethod
+    def wrap(cls, module: nn.Module, state_dict: dict, prefix: str):
+        """checkpoints written before the wrapper existed hold `<prefix><name>`; this module tree wants
+        `<prefix><name>.weight` (mmmm/utils.py:68-77)"""
+        for name, child in module.named_children():
+            if isinstance(child, cls) and (w := state_dict.pop(f'{prefix}{name}', None)) is not None:
+                state_dict[f'{prefix}{name}.weight'] = w
+
 
 class PatchEmbedding(nn.Module):
     def __init__(self, config: Namespace):
         super().__init__()
-        self.proj = Downsample(config.in_channels, config.hidden_size, config.patch_size)
+        self.proj = Downsample(config.in_channels, config.hidden_size, config.patch_size, interpolate_2d=True)
         self.pos_embed_shape = tuple(config.pos_embed_shape)
         self.cls_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size))
         self.cls_pos_embed = ParameterWrapper(torch.zeros(1, config.hidden_size))
         self.position_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size, *config.pos_embed_shape))
+        self.pt_pos_embed_shape = tuple(getattr(config, 'pt_pos_embed_shape', config.pos_embed_shape[-2:]))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """state-dict adapter (reference visual.py:37-57): an EVA2-CLIP / cogvlm-chat-hf checkpoint stores ONE 2-D table
+        `[1 + h*w, C]` (row 0 = cls); it becomes `cls_pos_embed [1, C]` + `position_embedding [1, C, d, h, w]` (the h x w
+        table resampled to this model's grid and repeated along depth). A PEFT modules_to_save copy saved at another grid
+        is resampled too."""
+        key = f'{prefix}position_embedding.weight'
+        saved = f'{prefix}position_embedding.modules_to_save.default.weight'
+        if (pe := state_dict.get(key)) is not None and pe.ndim == 2:
+            h, w = self.pt_pos_embed_shape
+            grid = pe[1:].reshape(h, w, -1).permute(2, 0, 1)[None]                 # [1, C, h, w]
+            if (h, w) != tuple(self.pos_embed_shape[-2:]):
+                grid = resample(grid, self.pos_embed_shape[-2:])
+            del state_dict[key]
+            state_dict[f'{prefix}cls_pos_embed'] = pe[0:1]
+            state_dict[f'{prefix}position_embedding'] = grid[:, :, None].expand(-1, -1, self.pos_embed_shape[0], -1, -1).contiguous()
+        elif (pe := state_dict.get(saved)) is not None and tuple(pe.shape[2:]) != tuple(self.position_embedding.weight.shape[2:]):
+            state_dict[saved] = resample(pe, self.position_embedding.weight.shape[2:])
+        ParameterWrapper.wrap(self, state_dict, prefix)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, image_list: list[torch.Tensor], patch_size_list: list[tuple]):
         """-> packed tokens [sum Nv, C], cu_seqlens (host list), grid shapes (visual.py:59-77)"""

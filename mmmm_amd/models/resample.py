@@ -36,14 +36,41 @@ def resample(x: torch.Tensor, shape, scale: bool = False) -> torch.Tensor:
 class Downsample(nn.Module):
     """parameters named like nn.Conv3d: weight [out, in, kz, ky, kx], bias [out]"""
 
-    def __init__(self, in_channels: int, out_channels: int, kernel_size, bias: bool = True):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, bias: bool = True, inflation: str = 'mean',
+                 interpolate_2d: bool = False):
         super().__init__()
         if isinstance(kernel_size, int):
             kernel_size = (kernel_size,) * 3
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, tuple(kernel_size)
+        self.inflation, self.interpolate_2d = inflation, interpolate_2d
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         nn.init.normal_(self.weight, std=0.02)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """2-D -> 3-D kernel inflation at load time (reference resample.py:31-53): a `[out, in, ky, kx]` kernel becomes
+        `[out, in, kz, ky, kx]` — 'mean': every depth slice = w / kz (a constant volume gives the 2-D response);
+        'center': the middle slice (or the two middle slices, halved) carries w."""
+        key = f'{prefix}weight'
+        w = state_dict.get(key)
+        if w is not None and w.ndim + 1 == self.weight.ndim:
+            if tuple(w.shape[2:]) != tuple(self.kernel_size[1:]) and self.interpolate_2d:
+                w = resample(w, self.kernel_size[1:], scale=True)
+            kz = self.kernel_size[0]
+            if self.inflation == 'mean':
+                w = (w / kz)[:, :, None].expand(-1, -1, kz, -1, -1).contiguous()
+            elif self.inflation == 'center':
+                vol = w.new_zeros(*w.shape[:2], kz, *w.shape[2:])
+                if kz % 2:
+                    vol[:, :, kz // 2] = w
+                else:
+                    vol[:, :, kz // 2 - 1] = w / 2
+                    vol[:, :, kz // 2] = w / 2
+                w = vol
+            else:
+                raise ValueError(self.inflation)
+            state_dict[key] = w
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def folded_weight(self, patch_z: int) -> torch.Tensor:
         w = self.weight

@@ -21,6 +21,35 @@ class PatchEmbeddingBlock(nn.Module):
         self.position_embeddings = ParameterWrapper(torch.zeros(1, hidden_size, *pos_embed_shape))
         self.pt_in_channels, self.pt_patch_size, self.pt_pos_embed_shape = pt_in_channels, pt_patch_size, pt_pos_embed_shape
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """state-dict adapter (reference image_encoder.py:82-119). A SegVol checkpoint holds the patch embedding as a
+        Linear over flattened `(p0 p1 p2 ci)` patches plus a `[1, d*h*w, C]` position table: the Linear becomes the conv
+        kernel `[co, ci, p0, p1, p2]` (resampled when the patch size differs, a 1-channel kernel spread over the input
+        channels), the table becomes `[1, C, d, h, w]` resampled to this model's grid. A table saved by this code base at
+        another grid is resampled as well."""
+        lin = f'{prefix}patch_embeddings.1.weight'
+        pos_key = f'{prefix}position_embeddings'
+        grid = tuple(self.position_embeddings.weight.shape[2:])
+        if (w := state_dict.get(lin)) is not None and w.ndim == 2:
+            del state_dict[lin]
+            p0, p1, p2 = self.pt_patch_size
+            ci = self.pt_in_channels
+            w = w.reshape(w.shape[0], p0, p1, p2, ci).permute(0, 4, 1, 2, 3)
+            if tuple(self.pt_patch_size) != tuple(self.proj.kernel_size):
+                w = resample(w, self.proj.kernel_size, scale=True)
+            if ci == 1 and self.proj.in_channels != 1:
+                w = w.expand(-1, self.proj.in_channels, -1, -1, -1) / self.proj.in_channels
+            state_dict[f'{prefix}proj.weight'] = w.contiguous()
+            state_dict[f'{prefix}proj.bias'] = state_dict.pop(f'{prefix}patch_embeddings.1.bias')
+            d, h, w_ = self.pt_pos_embed_shape
+            pe = state_dict[pos_key]
+            pe = pe.reshape(1, d, h, w_, pe.shape[-1]).permute(0, 4, 1, 2, 3)
+            state_dict[pos_key] = resample(pe, grid).contiguous()
+        elif (pe := state_dict.get(f'{pos_key}.weight')) is not None and tuple(pe.shape[2:]) != grid:
+            state_dict[f'{pos_key}.weight'] = resample(pe, grid)
+        ParameterWrapper.wrap(self, state_dict, prefix)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward(self, image_list, patch_size_list):
         xs, shapes = [], []
         pos_cache: dict[tuple, torch.Tensor] = {}

@@ -64,6 +64,20 @@ class MaskDecoder(nn.Module):
         self.output_hypernetworks_mlps = nn.ModuleList([MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(2)])
         self.txt_align_upscaled_embedding = Linear(transformer_dim, transformer_dim // 8)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """state-dict adapter (reference mask_decoder.py:76-87): SegVol stores the first upscaling LayerNorm as a per-voxel
+        affine `[C, d, h, w]` — reduced to its per-channel mean; a checkpoint with fewer mask tokens fills the leading
+        rows of this model's (freshly initialised) table."""
+        ln = f'{prefix}output_upscaling.1.'
+        if (w := state_dict.get(f'{ln}weight')) is not None and w.ndim == 4:
+            state_dict[f'{ln}weight'] = w.flatten(1).mean(dim=1)
+            state_dict[f'{ln}bias'] = state_dict[f'{ln}bias'].flatten(1).mean(dim=1)
+        if (pt := state_dict.get(f'{prefix}mask_tokens.weight')) is not None:
+            table = self.mask_tokens.weight.detach().clone()
+            table[:pt.shape[0]] = pt.to(table.dtype)[:table.shape[0]]
+            state_dict[f'{prefix}mask_tokens.weight'] = table[:self.num_mask_tokens]
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward(self, image_embeddings: torch.Tensor, image_pe: torch.Tensor, sparse_prompt_embeddings: torch.Tensor,
                 dense_prompt_embeddings: torch.Tensor, text_embedding: torch.Tensor, patch_size_z: int, grid: tuple,
                 need_masks: bool = True):

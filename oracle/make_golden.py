@@ -310,12 +310,57 @@ def f9_lora_targets(R):
     torch.save(res, OUT / 'f9_lora_targets.pt')
 
 
+def f10_state_dict_adapters(R):
+    """load-time adapters: visual.py:37-57, resample.py:31-53, image_encoder.py:82-119, mask_decoder.py:76-87,
+    on synthetic checkpoints in identity-resample geometry (luolib.resample is unpinned)"""
+    import sys
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(10)
+    res = {}
+    # 1. CogVLM patch embedding: 2-D position table + 2-D conv kernel + unwrapped parameter names
+    cfg = Namespace(in_channels=3, hidden_size=8, patch_size=(4, 2, 2), pos_embed_shape=(2, 3, 4), pt_pos_embed_shape=(3, 4))
+    pe = R.visual.PatchEmbedding(cfg)
+    ckpt = {'position_embedding.weight': torch.randn(1 + 12, 8, generator=g), 'proj.weight': torch.randn(8, 3, 2, 2, generator=g),
+            'proj.bias': torch.randn(8, generator=g), 'cls_embedding': torch.randn(1, 8, generator=g)}
+    pe.load_state_dict({k: v.clone() for k, v in ckpt.items()}, strict=False)
+    res['patch_embedding'] = dict(cfg=vars(cfg), ckpt=ckpt, loaded={k: v.detach().clone() for k, v in pe.state_dict().items()})
+    # 2. Downsample 'center' inflation, odd and even depth
+    for kz in (3, 4):
+        ds = R.resample.Downsample(2, 5, (kz, 2, 2), inflation='center')
+        w2 = torch.randn(5, 2, 2, 2, generator=g)
+        ds.load_state_dict({'weight': w2.clone(), 'bias': torch.zeros(5)})
+        res[f'downsample_center_{kz}'] = dict(weight_2d=w2, loaded=ds.weight.detach().clone())
+    # 3. SAM patch embedding block from a SegVol-style checkpoint (Linear over flattened patches, flat position table)
+    ie = sys.modules['mmmm.models.segvol.modeling.image_encoder']
+    blk = ie.PatchEmbeddingBlock(in_channels=3, patch_size=(2, 4, 4), pos_embed_shape=(2, 2, 3), hidden_size=8, num_heads=2, dropout_rate=0.0,
+                                 pt_in_channels=1, pt_patch_size=(2, 4, 4), pt_pos_embed_shape=(2, 2, 3))
+    ckpt = {'patch_embeddings.1.weight': torch.randn(8, 2 * 4 * 4 * 1, generator=g), 'patch_embeddings.1.bias': torch.randn(8, generator=g),
+            'position_embeddings': torch.randn(1, 12, 8, generator=g)}
+    blk.load_state_dict({k: v.clone() for k, v in ckpt.items()}, strict=False)
+    res['sam_patch_embedding'] = dict(ckpt=ckpt, loaded={k: v.detach().clone() for k, v in blk.state_dict().items()})
+    # 4. mask decoder: per-voxel LayerNorm affine + shorter mask-token table
+    md_mod = sys.modules['mmmm.models.segvol.modeling.mask_decoder']
+    tr = sys.modules['mmmm.models.segvol.modeling.transformer']
+    dec = md_mod.MaskDecoder(transformer_dim=16, transformer=tr.TwoWayTransformer(depth=1, embedding_dim=16, mlp_dim=32, num_heads=2),
+                             num_instances=6)
+    init_tokens = dec.mask_tokens.weight.detach().clone()
+    ckpt = {'output_upscaling.1.weight': torch.randn(4, 2, 3, 3, generator=g), 'output_upscaling.1.bias': torch.randn(4, 2, 3, 3, generator=g),
+            'mask_tokens.weight': torch.randn(4, 16, generator=g)}
+    dec.load_state_dict({k: v.clone() for k, v in ckpt.items()}, strict=False)
+    res['mask_decoder'] = dict(ckpt=ckpt, init_tokens=init_tokens, ln_weight=dec.output_upscaling[1].weight.detach().clone(),
+                               ln_bias=dec.output_upscaling[1].bias.detach().clone(), mask_tokens=dec.mask_tokens.weight.detach().clone())
+    torch.save(res, OUT / 'f10_adapters.pt')
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shims.load()
-    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets):
+    only = os.environ.get('GOLDEN_ONLY')
+    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters):
+        if only and only not in fn.__name__:
+            continue
         fn(R)
         print('wrote', fn.__name__)
     for p in sorted(OUT.glob('*.pt')):
