@@ -26,33 +26,41 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // double buffer = 64 KiB
 
 // Issue the LDS-DMA loads of one 128x64 bf16 operand tile. `rsrc` covers the tile's valid rows
 // (rows past the end read as zero), `ld_bytes` is the row pitch, `koff` the byte offset of the K-tile.
+template <int ROWS = 128>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld_bytes, int koff,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int PW = ROWS / 32;   // wave-instructions (8 rows each) per wave
   const int r8 = lane >> 3, slot = lane & 7;
   const int chunk = slot ^ r8;  // source chunk that lands in LDS slot `slot` of row (.. + r8)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + r8;
+  for (int i = 0; i < PW; ++i) {
+    const int row = (wave * PW + i) * 8 + r8;
     const int voff = row * ld_bytes + chunk * 16;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_tile + (wave * 4 + i) * 1024), 16, voff, koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_tile + (wave * PW + i) * 1024), 16, voff, koff, 0, 0);
   }
 }
 
 // ESZ = 2: bf16 operands, v_mfma_f32_16x16x32_bf16, K-tile 64.
 // ESZ = 4: f32 operands, v_mfma_f32_16x16x4_f32 (exact f32 fma chain), K-tile 32. Same 128-byte LDS rows.
-template <int ESZ, bool OUT_F32>
+// BMT = 128: 4 waves 2x2, wave tile 64 x 64.  BMT = 64 (fp32 output only): 4 waves 1x4, wave tile 64 rows x 32 columns —
+// twice the workgroups for the M ~ 3k fp32 linears of SAM / iSAM, whose 128-row grids (150 tiles) leave 40 % of the CUs idle.
+template <int ESZ, bool OUT_F32, int BMT = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
+  static_assert(BMT == 128 || (BMT == 64 && OUT_F32), "the 64-row tile has the direct fp32 epilogue only");
   constexpr int BKE = 128 / ESZ;  // K elements per tile
+  constexpr int NI = BMT == 128 ? 4 : 2;                 // 16-wide n sub-tiles per wave
+  constexpr int A_TILE = BMT * 128;                      // activation tile bytes
+  constexpr int STAGE = A_TILE + TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BMT == 128 ? wave >> 1 : 0, wn = BMT == 128 ? wave & 1 : wave;
 
   int tm, tn;
   gemm_tile_id(p, tm, tn);
   int row0, nrows, seg;
-  gemm_tile_rows<BM>(p, tm, row0, nrows, seg);
+  gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
   if (nrows <= 0) return;
   const int n0 = tn * BN;
   const int ncols = min(BN, p.N - n0);
@@ -80,9 +88,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     rB2 = make_rsrc(B2w, (int64_t)n0 * ldb2_b, ncols * ldb2_b);
   }
 
-  f32x4_t acc[4][4];  // [n-subtile i][m-subtile j]
+  f32x4_t acc[NI][4];  // [n-subtile i][m-subtile j]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -109,50 +117,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     constexpr bool EXT_NEXT = decltype(ext_next_tag)::value;      // tile t+1 is an extension tile
     const int buf = t & 1;
     if (HN) {
-      char* sa = smem + (buf ^ 1) * STAGE_BYTES;
-      char* sb = sa + TILE_BYTES;
+      char* sa = smem + (buf ^ 1) * STAGE;
+      char* sb = sa + A_TILE;
       if (EXT_NEXT) {
-        stage_tile(rA2, lda2_b, (t + 1) * 128, sa, wave, lane);
+        stage_tile<BMT>(rA2, lda2_b, (t + 1) * 128, sa, wave, lane);
         stage_tile(rB2, ldb2_b, (t + 1) * 128, sb, wave, lane);
       } else {
         const int koff = (t + 1 - kt_ext) * 128;
-        stage_tile(rA, lda_b, koff, sa, wave, lane);
+        stage_tile<BMT>(rA, lda_b, koff, sa, wave, lane);
         stage_tile(rB, ldb_b, koff, sb, wave, lane);
       }
     }
-    const char* sa = smem + buf * STAGE_BYTES + wm * (64 * 128);
-    const char* sb = smem + buf * STAGE_BYTES + TILE_BYTES + wn * (64 * 128);
+    const char* sa = smem + buf * STAGE + wm * (64 * 128);
+    const char* sb = smem + buf * STAGE + A_TILE + wn * (NI * 16 * 128);
     if (ESZ == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = ks ? off_k1 : off_k0;
-        bf16x8_t xa[4], wb[4];
+        bf16x8_t xa[4], wb[NI];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const bf16x8_t*>(sa + j * 2048 + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wb[i] = *reinterpret_cast<const bf16x8_t*>(sb + i * 2048 + off);
+        for (int i = 0; i < NI; ++i) wb[i] = *reinterpret_cast<const bf16x8_t*>(sb + i * 2048 + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], xa[j], acc[i][j], 0, 0, 0);
       }
     } else {
-      f32x4_t xa[4][2], wb[4][2];
+      f32x4_t xa[4][2], wb[NI][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         xa[j][0] = *reinterpret_cast<const f32x4_t*>(sa + j * 2048 + off_k0);
         xa[j][1] = *reinterpret_cast<const f32x4_t*>(sa + j * 2048 + off_k1);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         wb[i][0] = *reinterpret_cast<const f32x4_t*>(sb + i * 2048 + off_k0);
         wb[i][1] = *reinterpret_cast<const f32x4_t*>(sb + i * 2048 + off_k1);
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s >> 2][s & 3], xa[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
@@ -164,13 +172,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     // end of the LoRA extension: scale, and (dgrad) apply the inverted-dropout mask of the forward's LoRA input
     if (p.drop_p > 0.f) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          gemm_ext_scale4<true>(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * 64 + i * 16 + fq * 4, acc[i][j]);
+          gemm_ext_scale4<true>(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * (NI * 16) + i * 16 + fq * 4, acc[i][j]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] *= p.alpha2;
     }
@@ -179,11 +187,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   const std::false_type F_{};
 
   if (kt_ext > 0) {
-    stage_tile(rA2, lda2_b, 0, smem, wave, lane);
-    stage_tile(rB2, ldb2_b, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<BMT>(rA2, lda2_b, 0, smem, wave, lane);
+    stage_tile(rB2, ldb2_b, 0, smem + A_TILE, wave, lane);
   } else {
-    stage_tile(rA, lda_b, 0, smem, wave, lane);
-    stage_tile(rB, ldb_b, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<BMT>(rA, lda_b, 0, smem, wave, lane);
+    stage_tile(rB, ldb_b, 0, smem + A_TILE, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // tile 0 landed
@@ -208,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
       const int ml = wm * 64 + j * 16 + frow;
       if (ml >= nrows) continue;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int nl = wn * 64 + i * 16 + fq * 4;
+      for (int i = 0; i < NI; ++i) {
+        const int nl = wn * (NI * 16) + i * 16 + fq * 4;
         if (nl >= ncols) continue;
         if (!splitk) { gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]); continue; }
         // split-K partial: atomically accumulated; bias / residual enter once, with the first K range
@@ -229,27 +237,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     typedef EpiSlab<64, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
     const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
-    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
+    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * (NI * 16) >= 64 && ((uintptr_t)bias & 7) == 0;
     if (fast_bias) {
       f32x4_t bv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) bv[i] = epi_bias4(bias, n0 + wn * 64 + i * 16 + fq * 4);
+      for (int i = 0; i < NI; ++i) bv[i] = epi_bias4(bias, n0 + wn * (NI * 16) + i * 16 + fq * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
           epi_put4<2>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, 0, 4, acc[i][j], bv[i]);
     } else
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int nl = wn * 64 + i * 16 + fq * 4;
+      for (int i = 0; i < NI; ++i) {
+        const int nl = wn * (NI * 16) + i * 16 + fq * 4;
         if (plain) epi_put4<0>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
         else epi_put4<1>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
       }
     // same-wave LDS round trip: the compiler orders the ds_reads behind the ds_writes (lgkmcnt)
-    epi_flush<64, 64>(slab, p, row0 + wm * 64, n0 + wn * 64, nrows - wm * 64, ncols - wn * 64, lane);
+    epi_flush<64, 64>(slab, p, row0 + wm * 64, n0 + wn * (NI * 16), nrows - wm * 64, ncols - wn * (NI * 16), lane);
   }
 }
 
@@ -397,7 +405,11 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
     p.kchunk = per * bke;
     p.ksplit = (kt + per - 1) / per;
   }
-  p.tiles_m = (a->M + BM - 1) / BM + (segmented ? 1 : 0);
+  // fp32 operands with fewer 128-row tiles than CUs: 64-row tiles (twice the workgroups)
+  const bool bm64 = esz == 4 && p.ksplit <= 1 && a->M > 64 &&
+                    (int64_t)((a->M + BM - 1) / BM + (segmented ? 1 : 0)) * ((a->N + BN - 1) / BN) < 256;
+  const int bm = bm64 ? 64 : BM;
+  p.tiles_m = (a->M + bm - 1) / bm + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   const int grid = p.tiles_m * p.tiles_n;
@@ -408,7 +420,9 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (esz == 2 && p.ksplit <= 1 && use_tile256(a->M, a->N, a->K + a->K2, segmented)) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, stream);
     if (rc != VM_OK) return rc;
-  } else if (esz == 4)
+  } else if (esz == 4 && bm64)
+    hipLaunchKernelGGL((gemm_nt_k<4, true, 64>), dim3(grid, 1), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
+  else if (esz == 4)
     hipLaunchKernelGGL((gemm_nt_k<4, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else if (a->out_dtype == VM_F32)
     hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
