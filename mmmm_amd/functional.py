@@ -345,6 +345,35 @@ class _AttentionF32(Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+class _SelfAttentionF32(Function):
+    """fp32 self-attention on a packed qkv [T, 3*H*hd] (SAM ViT-B, image_encoder.py:126-136): q/k/v are strided views in
+    both directions and the gradient is ONE dqkv tensor written in place by the kernels — no contiguous copies of the
+    thirds, no zero-filled slice gradients, no accumulation adds."""
+    @staticmethod
+    def forward(ctx, qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen):
+        Cw = n_heads * head_dim
+        qkv = qkv if qkv.stride(-1) == 1 else qkv.contiguous()
+        out, lse = K.attn_f32_fwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+        ctx.save_for_backward(qkv, out, lse, cu_seqlens)
+        ctx.cfg = (n_heads, head_dim, scale, max_seqlen)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        qkv, out, lse, cu = ctx.saved_tensors
+        n_heads, head_dim, scale, max_seqlen = ctx.cfg
+        Cw = n_heads * head_dim
+        dqkv = torch.empty_like(qkv)      # every row belongs to a sequence: the dq / dkv kernels write all of it
+        K.attn_f32_bwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], out, lse, dout, n_heads, head_dim, scale, cu, max_seqlen,
+                       grads=(dqkv[:, :Cw], dqkv[:, Cw:2 * Cw], dqkv[:, 2 * Cw:]))
+        return dqkv, None, None, None, None, None
+
+
+def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen):
+    return _SelfAttentionF32.apply(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+
+
 def attention_f32(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen=None):
     """dense batched [Bn, L, H*hd] or packed var-len [T, H*hd] (+cu_seqlens) fp32 attention"""
     return _AttentionF32.apply(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)

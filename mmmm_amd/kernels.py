@@ -498,11 +498,18 @@ def attn_f32_fwd(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=
     return out, lse
 
 
-def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None):
+def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None,
+                 grads=None):
+    """`grads`: optional (dq, dk, dv) destinations with the SAME strides as q / k / v (the kernel addresses them with the
+    operands' strides), e.g. the thirds of one packed dqkv"""
     dout = _c(dout)
-    dq, dk, dv = torch.zeros_like(q, memory_format=torch.contiguous_format), torch.zeros_like(k, memory_format=torch.contiguous_format), \
-        torch.zeros_like(v, memory_format=torch.contiguous_format)
-    q, k, v = _c(q), _c(k), _c(v)
+    if grads is not None:
+        dq, dk, dv = grads
+        assert all(g.stride() == t.stride() for g, t in zip(grads, (q, k, v)))
+    else:
+        dq, dk, dv = torch.zeros_like(q, memory_format=torch.contiguous_format), torch.zeros_like(k, memory_format=torch.contiguous_format), \
+            torch.zeros_like(v, memory_format=torch.contiguous_format)
+        q, k, v = _c(q), _c(k), _c(v)
     a = _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens)
     if cu_seqlens is not None and max_seqlen is not None:
         a.Lq = a.Lk = max_seqlen

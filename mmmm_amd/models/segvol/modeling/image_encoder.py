@@ -71,11 +71,9 @@ class SABlock(nn.Module):
         self.out_proj = Linear(hidden_size, hidden_size)
         self.qkv = Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
 
-    def forward(self, x, cu, max_len):
-        qkv = self.qkv(x)
-        C = self.num_heads * self.head_dim
-        out = Fh.attention_f32(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], self.num_heads, self.head_dim, self.scale, cu, max_len)
-        return self.out_proj(out)
+    def forward(self, x, cu, max_len, residual=None):
+        out = Fh.self_attention_f32(self.qkv(x), self.num_heads, self.head_dim, self.scale, cu, max_len)
+        return self.out_proj(out, residual=residual)
 
 
 class MLPBlock(nn.Module):
@@ -84,8 +82,8 @@ class MLPBlock(nn.Module):
         self.linear1 = Linear(hidden_size, mlp_dim)
         self.linear2 = Linear(mlp_dim, hidden_size)
 
-    def forward(self, x):
-        return self.linear2(Fh.gelu(self.linear1(x)))
+    def forward(self, x, residual=None):
+        return self.linear2(Fh.gelu(self.linear1(x)), residual=residual)
 
 
 class TransformerBlock(nn.Module):
@@ -98,8 +96,9 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, cu, max_len):
         n1, n2 = self.norm1, self.norm2
-        x = x + self.attn(Fh.layer_norm(x, n1.weight, n1.bias, n1.eps), cu, max_len)
-        return x + self.mlp(Fh.layer_norm(x, n2.weight, n2.bias, n2.eps))
+        # the residual adds ride in the out_proj / linear2 GEMM epilogues
+        x = self.attn(Fh.layer_norm(x, n1.weight, n1.bias, n1.eps), cu, max_len, residual=x)
+        return self.mlp(Fh.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x)
 
 
 class ImageEncoderViT(nn.Module):

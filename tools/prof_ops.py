@@ -20,7 +20,7 @@ def step():
     loss = model.training_step(batch)
     loss.backward()
     ddp.finish()
-    torch.nn.utils.clip_grad_norm_(trainable, 1.0, foreach=True)
+    ddp.clip_grad_norm_(1.0)
     opt.step()
 
 step(); step()
