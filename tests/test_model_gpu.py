@@ -241,3 +241,45 @@ def test_resident_lora_transposes_match_per_use_transposes(dev, lm):
         mods[0].A.div_(1.5)
     for m in mods:
         m._lora_t = None
+
+
+# ------------------------------------------------------------------ true widths (one layer each)
+def test_true_width_layers_match_oracle(dev):
+    """One decoder layer at h=4096 / i=11008 / 32 heads of 128 and one ViT layer at d=1792 / f=15360 / 16 heads of 112
+    (the widths of BASELINE configs[1]) on a 320x320 image + 96 text tokens: the shapes at which the 2-segment GEMM,
+    the LoRA split-K / skinny kernels and the hd-128 / hd-112 attention run in production, against the fp32 oracle."""
+    from mmmm_amd.models.cogvlm.configuration_cogvlm import CogVLMConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, VisionArgs
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.utils import apply_lora
+    from mmmm_amd.data.synthetic import SpecialTokens, make_batch
+    cfg = CogVLMConfig(vocab_size=2056, hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
+                       vision_config=dict(in_channels=3, hidden_size=1792, num_heads=16, num_hidden_layers=1, intermediate_size=15360,
+                                          layer_norm_eps=1e-6, patch_size=(16, 16, 16), pos_embed_shape=(2, 20, 20)))
+    m = MMMMForCausalLM(cfg, vision_override=VisionArgs(pos_embed_shape=(2, 20, 20), patch_size=16))
+    apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    randomize_(m, 321)
+    with torch.no_grad():
+        # keep the first ViT layer out of softmax saturation: with unit-variance random kernels the z-folded 2-D patch
+        # embedding has std ~33, q.k scores in the hundreds, one-hot attention, and dq / dk become pure cancellation noise
+        # (P (dP - delta) ~ 0) that no bf16-vs-fp32 comparison can resolve
+        m.model.vision.patch_embedding.proj.weight.mul_(0.03)
+    m.to(dev).to(torch.bfloat16).train()
+    tok = SpecialTokens(base_vocab=2048)
+    batch = make_batch([(3, 1, 320, 320), (3, 1, 320, 320)], [(1, 16, 16)] * 2, [(1, 2, 2)] * 2, [96, 61], tok=tok, seed=3, device=dev)
+    out = m(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
+    out.loss.backward()
+    ref, sd = run_oracle(m, batch, need_grad=True)
+    ref.loss.backward()
+    assert abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()) < 5e-3
+    worst = {}
+    for name, p in m.named_parameters():
+        if not p.requires_grad or p.grad is None:
+            continue
+        g_ref = sd[name].grad
+        if g_ref is None or g_ref.norm() == 0:
+            continue
+        worst[name] = rel(p.grad.float(), g_ref)
+    assert len(worst) > 30
+    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
