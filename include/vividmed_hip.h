@@ -240,11 +240,12 @@ int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
  *   transpose_out == 0: out[c][n] (C rows, 64 columns, ldo)   = [accumulate ? out : 0] + alpha * sum_m W[m][c] S[m][n]
  *   transpose_out == 1: out[n][c] (64 rows, C columns, ldo)   = the same, stored transposed
  * drop_p > 0 applies the inverted-dropout mask of element (m, c) of an [*, C] tensor to W (same hash as vm_dropout).
- * Rows: all M, a routed segment (counts_dev + segment as in vm_gemm_tn_bf16) or nrows_dev. Partial sums over row
+ * Rows: all M, a routed segment (counts_dev + segment as in vm_gemm_tn_bf16) or nrows_dev; segment == 2 computes BOTH
+ * routed segments in one launch: segment 0 -> out, segment 1 -> out1 (the two experts of a gated linear). Partial sums over row
  * ranges go through `workspace` (size from vm_tn_skinny_workspace) and are added in a fixed order: deterministic.
  * C % 8 == 0, ldw % 8 == 0, lds % 8 == 0. out_dtype VM_BF16 or VM_F32. */
 int vm_tn_skinny_workspace(int M, int C, int64_t* bytes_host);
-int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, int64_t ldo, int out_dtype,
+int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, void* out1, int64_t ldo, int out_dtype,
                       int transpose_out, int accumulate, int M, const int32_t* counts_dev, int segment,
                       const int32_t* nrows_dev, float alpha, float drop_p, uint64_t drop_seed, void* workspace,
                       int64_t workspace_bytes, void* stream);

@@ -332,8 +332,9 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
   if (p.counts_dev) {
     const int k0 = __builtin_amdgcn_readfirstlane(p.counts_dev[0]);
     const int k1 = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
-    if (p.segment == 0) { rb = 0; re = min(k0, k1); }
-    else if (p.segment == 1) { rb = min(k0, k1); re = k1; }
+    const int seg = p.segment == 2 ? (int)blockIdx.z : p.segment;      // 2: both segments in one launch (grid.z)
+    if (seg == 0) { rb = 0; re = min(k0, k1); }
+    else if (seg == 1) { rb = min(k0, k1); re = k1; }
     else { rb = 0; re = k1; }
   } else if (p.nrows_dev) {
     re = min(p.M, __builtin_amdgcn_readfirstlane(p.nrows_dev[0]));
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-row tail stages before the LDS is released
   // partial tile: ws[split][c][n], n fastest
   const int h = lane >> 5;
-  float* w = p.ws + ((int64_t)blockIdx.y * p.c_pad + c0 + wc * 32) * 64 + 32 * wn + (lane & 31);
+  float* w = p.ws + ((int64_t)(blockIdx.z * p.splits + blockIdx.y) * p.c_pad + c0 + wc * 32) * 64 + 32 * wn + (lane & 31);
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -408,8 +409,9 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
 // the transposed form goes through LDS so that a thread writes 4 consecutive c
 template <typename TO>
 __global__ __launch_bounds__(256) void tn_reduce_k(const float* __restrict__ ws, int c_pad, int C, int splits, TO* __restrict__ out,
-                                                   int64_t ldo, int transpose_out, int accumulate, float alpha) {
+                                                   TO* __restrict__ out1, int64_t ldo, int transpose_out, int accumulate, float alpha) {
   __shared__ float tile[64][17];
+  if (blockIdx.y) { out = out1; ws += (int64_t)splits * c_pad * 64; }      // second row segment of the merged form
   const int c0 = blockIdx.x * 16;
   const int tid = threadIdx.x;
   const int cl = tid >> 4, n4 = (tid & 15) * 4;
@@ -539,11 +541,11 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
 int vm_tn_skinny_workspace(int M, int C, int64_t* bytes_host) {
   if (!bytes_host || M <= 0 || C <= 0) return VM_ERR_BAD_ARG;
   const int c_pad = (C + 127) / 128 * 128;
-  *bytes_host = (int64_t)tn_skinny_splits(M, C) * c_pad * 64 * 4;
+  *bytes_host = 2 * (int64_t)tn_skinny_splits(M, C) * c_pad * 64 * 4;      // room for the two-segment form
   return VM_OK;
 }
 
-int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, int64_t ldo, int out_dtype,
+int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t lds, void* out, void* out1, int64_t ldo, int out_dtype,
                       int transpose_out, int accumulate, int M, const int32_t* counts_dev, int segment,
                       const int32_t* nrows_dev, float alpha, float drop_p, uint64_t drop_seed, void* workspace,
                       int64_t workspace_bytes, void* stream) {
@@ -557,23 +559,25 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
   p.S = (const unsigned short*)S; p.lds = lds;
   p.M = M;
   p.counts_dev = counts_dev; p.segment = counts_dev ? segment : -1;
+  const int nseg = p.segment == 2 ? 2 : 1;
+  if (nseg == 2 && !out1) return VM_ERR_BAD_ARG;
   p.nrows_dev = nrows_dev;
   p.splits = tn_skinny_splits(M, C);
   p.c_pad = (C + 127) / 128 * 128;
-  if (workspace_bytes < (int64_t)p.splits * p.c_pad * 64 * 4) return VM_ERR_BAD_ARG;
+  if (workspace_bytes < (int64_t)nseg * p.splits * p.c_pad * 64 * 4) return VM_ERR_BAD_ARG;
   p.ws = (float*)workspace;
   p.drop_p = drop_p; p.seed = drop_seed;
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  if (tn_skinny_bc(C) == 128) hipLaunchKernelGGL(tn_skinny_k<128>, dim3(p.c_pad / 128, p.splits), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(tn_skinny_k<64>, dim3(p.c_pad / 64, p.splits), dim3(256), 0, (hipStream_t)stream, p);
-  const dim3 rg(p.c_pad / 16);
+  if (tn_skinny_bc(C) == 128) hipLaunchKernelGGL(tn_skinny_k<128>, dim3(p.c_pad / 128, p.splits, nseg), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(tn_skinny_k<64>, dim3(p.c_pad / 64, p.splits, nseg), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 rg(p.c_pad / 16, nseg);
   if (out_dtype == VM_BF16)
     hipLaunchKernelGGL(tn_reduce_k<unsigned short>, rg, dim3(256), 0, (hipStream_t)stream, (const float*)p.ws, p.c_pad, C, p.splits,
-                       (unsigned short*)out, ldo, transpose_out, accumulate, alpha);
+                       (unsigned short*)out, (unsigned short*)out1, ldo, transpose_out, accumulate, alpha);
   else
     hipLaunchKernelGGL(tn_reduce_k<float>, rg, dim3(256), 0, (hipStream_t)stream, (const float*)p.ws, p.c_pad, C, p.splits,
-                       (float*)out, ldo, transpose_out, accumulate, alpha);
+                       (float*)out, (float*)out1, ldo, transpose_out, accumulate, alpha);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * (double)M * C * 64.0);
   VM_LAUNCH_CHECK();
   return VM_OK;

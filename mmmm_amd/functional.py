@@ -81,6 +81,23 @@ def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
                        out_dtype=param.dtype)
 
 
+def _lora_wgrad_pair(params, W, S, transpose_out, counts, scale, drop_p, seed):
+    """both experts of a gated linear in ONE launch (segment 0 -> params[0], segment 1 -> params[1]); returns the pair of
+    gradients for autograd (None where the kernel accumulated straight into the bucket view)."""
+    p0, p1 = params
+    r0, r1 = getattr(p0, '_vm_grad_ready', None), getattr(p1, '_vm_grad_ready', None)
+    direct = (r0 is not None and r1 is not None and p0.grad is not None and p1.grad is not None and p0.grad.dtype == p1.grad.dtype
+              and p0.grad.dtype in (torch.bfloat16, torch.float32) and p0.grad.stride() == p1.grad.stride())
+    if direct:
+        K.tn_skinny(W, S, transpose_out=transpose_out, out=(p0.grad, p1.grad), accumulate=True, counts=counts, segment=2, alpha=scale,
+                    drop_p=drop_p, drop_seed=seed)
+        r0(p0)
+        r1(p1)
+        return None, None
+    return K.tn_skinny(W, S, transpose_out=transpose_out, counts=counts, segment=2, alpha=scale, drop_p=drop_p, drop_seed=seed,
+                       out_dtype=p0.dtype)
+
+
 class _Linear(Function):
     """y = act(x W^T + s·(drop(x) A^T) B^T + b) + residual, optionally per row segment.
 
@@ -137,15 +154,21 @@ class _Linear(Function):
         # parameter gradients contract over token rows
         experts = ((0, W0, b0, A0, B0, 4), (1, W1, b1, A1, B1, 9)) if gated else ((0, W0, b0, A0, B0, 4),)
         tn_ok = x.dtype == torch.bfloat16 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+        # gated + LoRA on both experts: the two experts' factor gradients come out of one launch each (dB pair, dA pair)
+        paired = (gated and lora and tn_ok and need[8] and need[13] and need[7] and need[12]
+                  and K.tn_skinny_supported(dy, t) and K.tn_skinny_supported(x, u))
+        if paired:
+            g[8], g[13] = _lora_wgrad_pair((B0, B1), dy, t, False, cnt, s, 0.0, 0)
+            g[7], g[12] = _lora_wgrad_pair((A0, A1), x, u, True, cnt, s, meta.drop_p, meta.drop_seed)
         for e, W, b, A, B, base in experts:
             seg = e if gated else -1
             if tn_ok:
                 # row-contraction MFMA kernel on the row-major activations as they are: no transposed copies
                 if need[base]:
                     g[base] = K.gemm_tn(dy, x, counts=cnt, segment=seg)
-                if lora and need[base + 4]:                                   # dB [N, r] = s · dy^T · t
+                if lora and need[base + 4] and not paired:                    # dB [N, r] = s · dy^T · t
                     g[base + 4] = _lora_wgrad(B, dy, t, False, cnt, seg, s, 0.0, 0)
-                if lora and need[base + 3]:                                   # dA [r, K] = s · u^T · drop(x)
+                if lora and need[base + 3] and not paired:                    # dA [r, K] = s · u^T · drop(x)
                     g[base + 3] = _lora_wgrad(A, x, u, True, cnt, seg, s, meta.drop_p, meta.drop_seed)
             else:
                 # fp32 islands / odd shapes: K-contiguous transposes feed the NT kernel

@@ -195,20 +195,27 @@ def tn_skinny_supported(W: torch.Tensor, S: torch.Tensor) -> bool:
             and W.stride(1) == 1 and S.stride(1) == 1 and W.stride(0) % 8 == 0 and S.stride(0) % 8 == 0)
 
 
-def tn_skinny(W: torch.Tensor, S: torch.Tensor, *, transpose_out: bool, out: torch.Tensor | None = None, accumulate: bool = False,
+def tn_skinny(W: torch.Tensor, S: torch.Tensor, *, transpose_out: bool, out=None, accumulate: bool = False,
               counts: torch.Tensor | None = None, segment: int = -1, nrows: torch.Tensor | None = None, alpha: float = 1.0,
-              drop_p: float = 0.0, drop_seed: int = 0, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+              drop_p: float = 0.0, drop_seed: int = 0, out_dtype: torch.dtype | None = None):
     """LoRA factor gradient: out[c][n] (or out[n][c] when transpose_out) (+)= alpha * sum_m drop(W)[m][c] * S[m][n].
-    W [M, C] is the wide streamed operand, S [M, 64]; deterministic (workspace partials reduced in a fixed order)."""
+    W [M, C] is the wide streamed operand, S [M, 64]; deterministic (workspace partials reduced in a fixed order).
+    segment == 2 (with `counts`): both routed row segments in one launch; `out` is then a pair (segment 0, segment 1)."""
     M, Cw = W.shape
     assert S.shape == (M, 64)
+    shape = (64, Cw) if transpose_out else (Cw, 64)
+    both = segment == 2
     if out is None:
         assert not accumulate
-        out = torch.empty((64, Cw) if transpose_out else (Cw, 64), dtype=out_dtype or W.dtype, device=W.device)
-    assert out.shape == ((64, Cw) if transpose_out else (Cw, 64)) and out.stride(1) == 1
+        mk = lambda: torch.empty(shape, dtype=out_dtype or W.dtype, device=W.device)
+        out = (mk(), mk()) if both else mk()
+    o0, o1 = out if both else (out, None)
+    for o in (o0, o1):
+        assert o is None or (o.shape == shape and o.stride(1) == 1)
+    assert o1 is None or (o1.dtype == o0.dtype and o1.stride(0) == o0.stride(0))
     nbytes = _tn_skinny_ws_bytes(M, Cw)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=W.device)
-    hip.call('vm_tn_skinny_bf16', ptr(W), _ld(W), Cw, ptr(S), _ld(S), ptr(out), _ld(out), dtype_code(out.dtype), int(transpose_out),
+    hip.call('vm_tn_skinny_bf16', ptr(W), _ld(W), Cw, ptr(S), _ld(S), ptr(o0), ptr(o1), _ld(o0), dtype_code(o0.dtype), int(transpose_out),
              int(accumulate), M, ptr(counts), segment, ptr(nrows), alpha, drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, ptr(ws), nbytes, stream())
     return out
 

@@ -529,6 +529,12 @@ def test_tn_skinny_segments(dev, K):
     assert rel_err(K.tn_skinny(W, S, transpose_out=False, counts=counts, segment=-1, out_dtype=f), r0 + r1) < 1e-5
     n = torch.tensor([M], dtype=torch.int32, device=dev)
     assert rel_err(K.tn_skinny(W, S, transpose_out=True, nrows=n, out_dtype=f), (r0 + r1).T) < 1e-5
+    # both segments in one launch
+    o0, o1 = K.tn_skinny(W, S, transpose_out=False, counts=counts, segment=2, out_dtype=f)
+    assert rel_err(o0, r0) < 1e-5 and rel_err(o1, r1) < 1e-5
+    a0, a1 = torch.ones(64, Cw, device=dev), torch.full((64, Cw), 2.0, device=dev)
+    K.tn_skinny(W, S, transpose_out=True, counts=counts, segment=2, out=(a0, a1), accumulate=True, alpha=0.5)
+    assert rel_err(a0, 1 + 0.5 * r0.T) < 1e-5 and rel_err(a1, 2 + 0.5 * r1.T) < 1e-5
     empty = torch.tensor([0, 0, 0, 0], dtype=torch.int32, device=dev)
     assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
 
