@@ -16,6 +16,24 @@ from . import hip
 from . import kernels as K
 
 
+_CU_CACHE: dict = {}
+
+
+def cu_seqlens_tensor(lens, device) -> torch.Tensor:
+    """int32 prefix sums of `lens` on `device`, cached per (lens, device): a fresh torch.tensor(..., device=...) is a
+    blocking pageable host->device copy, i.e. a full host/GPU synchronisation in the middle of the forward pass"""
+    key = (tuple(int(n) for n in lens), str(device))
+    t = _CU_CACHE.get(key)
+    if t is None:
+        cu = [0]
+        for n in key[0]:
+            cu.append(cu[-1] + n)
+        if len(_CU_CACHE) > 256:
+            _CU_CACHE.clear()
+        t = _CU_CACHE[key] = torch.tensor(cu, dtype=torch.int32, device=device)
+    return t
+
+
 # ----------------------------------------------------------------------------- linear (plain / gated / LoRA)
 @dataclass
 class LinearMeta:

@@ -220,8 +220,7 @@ class CogVLMModel(nn.Module):
             feats = self.vision(image, patch_size, pool_size)
             tok = torch.arange(B * L, device=dev).view(B, L)
             img_tok = torch.cat([tok[i, 1:1 + f.shape[0]] for i, f in enumerate(feats)])
-            ids = ids.clone()
-            ids[img_tok] = -1
+            ids = ids.index_fill(0, img_tok, -1)          # (ids[img_tok] = -1 uploads the scalar: a blocking H2D copy)
         row_ids = torch.where(rt.tok_of_row >= 0, ids[rt.tok_of_row.clamp_min(0).long()], torch.full_like(ids, -1))
         x = Fh.embedding_rows(self.embed_tokens.weight, row_ids.contiguous())
         if feats is not None:

@@ -175,7 +175,7 @@ class EVA2CLIPModel(nn.Module):
         cu_host = [0]
         for n in lens:
             cu_host.append(cu_host[-1] + n)
-        cu = torch.tensor(cu_host, dtype=torch.int32, device=x.device)
+        cu = Fh.cu_seqlens_tensor(lens, x.device)
         x = self.transformer(x, cu, max(lens))
         pooled, counts = [], []
         for i, (shape, pool) in enumerate(zip(shapes, pool_size_list)):

@@ -33,6 +33,26 @@ class VisionArgs:
     patch_size: Any = 16
 
 
+class _HostCopy:
+    """device -> pinned host copy started early (non-blocking) and read late: by the time `get()` is called the copy has
+    long completed, so the host never waits for the kernels enqueued in between"""
+
+    def __init__(self, t: torch.Tensor):
+        if t.is_cuda:
+            self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self.host.copy_(t, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = t, None
+
+    def get(self) -> torch.Tensor:
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self.host
+
+
 @dataclass
 class VisualGroundingOutput:
     masks_logits: list = field(default_factory=list)
@@ -157,20 +177,32 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         return self.lm_head.weight.device
 
     # -- grounding -------------------------------------------------------------------------------
-    def _get_vg_prompts(self, token_ids, hidden_states, prompt_mask):
-        """mmmm.py:167-178: hidden states at </p> -> vg_proj (fp32)"""
-        eop_mask = token_ids == self.tokenizer.eop_token_id
-        x = hidden_states[eop_mask]
+    def _get_vg_prompts(self, token_ids, hidden_states, prompt_mask, token_ids_host=None):
+        """mmmm.py:167-178: hidden states at </p> -> vg_proj (fp32).
+        With `token_ids_host` (a host copy of token_ids started early in the step, see `_HostCopy`) the </p> positions
+        are found on the host and gathered by index: no boolean-mask indexing, i.e. no device->host synchronisation after
+        the language-model forward has been enqueued."""
+        eop = self.tokenizer.eop_token_id
+        if token_ids_host is not None:
+            th = token_ids_host.get()
+            mask_h = th == eop
+            counts = mask_h.sum(dim=-1).tolist()
+            idx = mask_h.flatten().nonzero().flatten().pin_memory().to(hidden_states.device, non_blocking=True)
+            x = hidden_states.reshape(-1, hidden_states.shape[-1]).index_select(0, idx)
+        else:
+            eop_mask = token_ids == eop
+            x = hidden_states[eop_mask]
+            counts = eop_mask.sum(dim=-1).tolist()
         x = self.vg_proj[2](Fh.relu(self.vg_proj[0](x)))
-        prompts = x.split(eop_mask.sum(dim=-1).tolist())
+        prompts = x.split(counts)
         return [p if m is None else p[m] for p, m in zip(prompts, prompt_mask)]
 
-    def visual_grounding(self, token_ids, hidden_states, image, patch_size, prompt_mask, instance_mask):
+    def visual_grounding(self, token_ids, hidden_states, image, patch_size, prompt_mask, instance_mask, token_ids_host=None):
         """mmmm.py:180-223"""
         if instance_mask is None:
             raise NotImplementedError
         B = len(image)
-        vg_prompts = self._get_vg_prompts(token_ids, hidden_states, prompt_mask)
+        vg_prompts = self._get_vg_prompts(token_ids, hidden_states, prompt_mask, token_ids_host)
         masks_logits: list = [None] * B
         boxes: list = [None] * B
         disc_logit: list = [None] * B
@@ -206,12 +238,17 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         """mmmm.py:225-285"""
         B = len(masks_logits)
         loss_list, log_dict = [], {}
+        # Hungarian matching of all instance samples with one device->host transfer
+        inst = [i for i in range(B) if boxes_label[i] is not None and masks_label[i] is None and disc_logit[i].shape[0] > 0]
+        matches = dict(zip(inst, self.isam_loss.match_samples(
+            [(boxes_reg[i], disc_logit[i], boxes_label[i], index_offsets[i]) for i in inst]))) if inst else {}
         for i in range(B):
             if boxes_label[i] is not None:
                 if masks_label[i] is not None:
                     raise NotImplementedError('instance segmentation is not supported yet')
                 dummy = boxes_reg[i].new_empty((*boxes_reg[i].shape[:2], 0, 0, 0))
-                loss_, log_ = self.isam_loss.compute_loss(dummy, dummy, boxes_reg[i], disc_logit[i], None, boxes_label[i], index_offsets[i])
+                loss_, log_ = self.isam_loss.compute_loss(dummy, dummy, boxes_reg[i], disc_logit[i], None, boxes_label[i], index_offsets[i],
+                                                          match=matches.get(i))
                 loss_ = loss_ + zero_loss(masks_logits[i])
             elif masks_label[i] is not None and masks_label[i].shape[0] > 0:
                 log_ = self.mask_loss(masks_logits[i][:, None], masks_label[i][:, None], return_dict=True)
@@ -249,6 +286,11 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         self._lora_transposes.refresh()          # one launch: K-contiguous LoRA factors for this step's backward
         vlm_inputs = batch['vlm_inputs']
         input_ids = vlm_inputs['input_ids']
+        # small integer tensors the host will need after the forward has been enqueued: copy them out NOW
+        ids_host = _HostCopy(input_ids[:, 1:]) if self.sam is not None else None
+        offs_host = None
+        if self.sam is not None and batch.get('index_offsets') is not None:
+            offs_host = [None if o is None else _HostCopy(o) for o in batch['index_offsets']]
         out: CausalLMOutputWithPast = self(**vlm_inputs, image=batch['image'], patch_size=batch['patch_size'],
                                            pool_size=batch['pool_size'], return_dict=True, output_hidden_states=True)
         if self.sam is None:
@@ -257,9 +299,10 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         B = input_ids.shape[0]
         masks_logits, boxes, disc_logit = self.visual_grounding(
             input_ids[:, 1:], out.hidden_states[-1][:, :-1].float(), batch['grounding_image'], batch['patch_size'],
-            batch.get('vg_label_mask') or [None] * B, batch['instance_mask'],
+            batch.get('vg_label_mask') or [None] * B, batch['instance_mask'], token_ids_host=ids_host,
         )
-        vg_loss, vg_log = self._compute_vg_loss(masks_logits, boxes, disc_logit, batch['masks'], batch['boxes'], batch['index_offsets'])
+        vg_loss, vg_log = self._compute_vg_loss(masks_logits, boxes, disc_logit, batch['masks'], batch['boxes'],
+                                                batch['index_offsets'] if offs_host is None else [None if o is None else o.get() for o in offs_host])
         loss = out.loss * self.lm_loss_weight + vg_loss
         logs = {'train/loss': loss, 'train/lm_loss': out.loss, 'train/vg_loss': vg_loss, **_add_prefix(vg_log, 'train/vg')}
         # per-token CE on the <p> / </p> targets: the unweighted row CE is already a by-product of the fused lm_head+CE

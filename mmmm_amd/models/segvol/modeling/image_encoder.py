@@ -118,7 +118,7 @@ class ImageEncoderViT(nn.Module):
         cu_host = [0]
         for n in lens:
             cu_host.append(cu_host[-1] + n)
-        cu = torch.tensor(cu_host, dtype=torch.int32, device=x.device)
+        cu = Fh.cu_seqlens_tensor(lens, x.device)
         for blk in self.blocks:
             if self.gradient_checkpointing and self.training and x.requires_grad:
                 x = checkpoint(blk, x, cu, max(lens), use_reentrant=False, preserve_rng_state=False)

@@ -117,12 +117,16 @@ def box_pair_giou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
     """monai.data.box_utils.box_pair_giou [external]: fp32, eps-regularised denominators"""
     eps = torch.finfo(torch.float32).eps
     b1, b2 = b1.float(), b2.float()
-    a1 = (b1[..., 3:] - b1[..., :3]).prod(-1)
-    a2 = (b2[..., 3:] - b2[..., :3]).prod(-1)
-    inter = (torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+
+    def vol(e):     # product of the 3 edge lengths, written out: Tensor.prod's backward inspects zeros on the HOST (a sync)
+        return e[..., 0] * e[..., 1] * e[..., 2]
+
+    a1 = vol(b1[..., 3:] - b1[..., :3])
+    a2 = vol(b2[..., 3:] - b2[..., :3])
+    inter = vol((torch.min(b1[..., 3:], b2[..., 3:]) - torch.max(b1[..., :3], b2[..., :3])).clamp(min=0))
     union = a1 + a2 - inter
     iou = inter / (union + eps)
-    enc = (torch.max(b1[..., 3:], b2[..., 3:]) - torch.min(b1[..., :3], b2[..., :3])).clamp(min=0).prod(-1)
+    enc = vol((torch.max(b1[..., 3:], b2[..., 3:]) - torch.min(b1[..., :3], b2[..., :3])).clamp(min=0))
     return iou - (enc - union) / (enc + eps)
 
 
@@ -155,10 +159,9 @@ class InstanceSamLoss(nn.Module):
         return {f'focal-{self.disc_focal_gamma:.1f}': d, 'total': total} if return_dict else total
 
     @torch.no_grad()
-    def _match_all(self, boxes_reg, disc_logit, boxes_label, index_offsets_host: list[tuple[int, int]]):
-        """box-only Hungarian matching of every target of one sample (reference _match_instances :178-250,
-        masks_label None, num_uncertain 0). Cost matrices are built on the device, copied to the host once."""
-        from scipy.optimize import linear_sum_assignment
+    def _match_costs(self, boxes_reg, disc_logit, boxes_label, index_offsets_host: list[tuple[int, int]]):
+        """device part of the box-only Hungarian matching of one sample (reference _match_instances :178-250, masks_label
+        None, num_uncertain 0): one cost matrix per target -> (costs, metas)"""
         nt, nq = disc_logit.shape
         costs, metas = [], []
         prob = disc_logit.sigmoid()
@@ -180,23 +183,58 @@ class InstanceSamLoss(nn.Module):
             cost = torch.cat([pair, disc_cost.new_zeros(nq, nneg)], dim=1) + disc_cost
             metas.append((len(costs), npos, cost.shape[1], s))
             costs.append(cost.float())
+        return costs, metas
+
+    @staticmethod
+    def _assign(host_costs, metas, nt: int, nq: int) -> torch.Tensor:
+        """host part: scipy linear_sum_assignment per target -> int64 [nt, nq] (target index | MATCH_NEGATIVE)"""
+        from scipy.optimize import linear_sum_assignment
         match = torch.full((nt, nq), MATCH_NEGATIVE, dtype=torch.int64)
+        for i, meta in enumerate(metas):
+            if meta is None:
+                continue
+            j, npos, ncol, off = meta
+            row, col = linear_sum_assignment(host_costs[j][:, :ncol])
+            m = torch.empty(nq, dtype=torch.int64)
+            m[torch.as_tensor(row)] = torch.as_tensor(col)
+            m[m >= npos] = MATCH_NEGATIVE
+            m[m >= 0] += off
+            match[i] = m
+        return match          # host tensor: the caller derives index tensors from it without touching the device
+
+    @torch.no_grad()
+    def match_samples(self, samples: list[tuple]) -> list[torch.Tensor]:
+        """Hungarian matching of SEVERAL samples [(boxes_reg [nt, 1 + nq, 6], disc_logit [nt, nq], boxes_label, index_offsets
+        (host))] with ONE device->host transfer of all their cost matrices (one synchronisation per step instead of one per
+        instance sample)."""
+        built = []
+        for boxes_reg, disc_logit, boxes_label, index_offsets in samples:
+            offs = [tuple(x) for x in index_offsets.tolist()]
+            built.append(self._match_costs(boxes_reg[:, 1:], disc_logit.float(), boxes_label, offs))
+        flat = [c for costs, _ in built for c in costs]
+        host = None
+        if flat:
+            width = max(c.shape[1] for c in flat)
+            rows = max(c.shape[0] for c in flat)
+            host = torch.stack([F.pad(c, (0, width - c.shape[1], 0, rows - c.shape[0])) for c in flat]).cpu().numpy()
+        out, k = [], 0
+        for (costs, metas), (boxes_reg, disc_logit, _, _) in zip(built, samples):
+            nt, nq = disc_logit.shape
+            part = [host[k + j][:nq] for j in range(len(costs))] if costs else []
+            k += len(costs)
+            out.append(self._assign(part, metas, nt, nq))
+        return out
+
+    def _match_all(self, boxes_reg, disc_logit, boxes_label, index_offsets_host: list[tuple[int, int]]):
+        costs, metas = self._match_costs(boxes_reg, disc_logit, boxes_label, index_offsets_host)
+        nt, nq = disc_logit.shape
+        host = []
         if costs:
             width = max(c.shape[1] for c in costs)
             host = torch.stack([F.pad(c, (0, width - c.shape[1])) for c in costs]).cpu().numpy()   # ONE device->host transfer
-            for i, meta in enumerate(metas):
-                if meta is None:
-                    continue
-                j, npos, ncol, off = meta
-                row, col = linear_sum_assignment(host[j][:, :ncol])
-                m = torch.empty(nq, dtype=torch.int64)
-                m[torch.as_tensor(row)] = torch.as_tensor(col)
-                m[m >= npos] = MATCH_NEGATIVE
-                m[m >= 0] += off
-                match[i] = m
-        return match.to(disc_logit.device)
+        return self._assign(host, metas, nt, nq)
 
-    def compute_loss(self, masks_logits, masks_logits_ds, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets):
+    def compute_loss(self, masks_logits, masks_logits_ds, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets, match=None):
         """reference :252-361, branch used by the training step (no instance masks)"""
         if masks_label is not None:
             raise NotImplementedError('instance segmentation labels are not supported yet (reference mmmm.py:239-241)')
@@ -207,24 +245,33 @@ class InstanceSamLoss(nn.Module):
         if nt > 0:
             boxes_reg = boxes_reg[:, 1:]
             disc_logit = disc_logit.float()
-            offs = [tuple(x) for x in index_offsets.tolist()]
-            match = self._match_all(boxes_reg, disc_logit, boxes_label, offs)
-            pos, neg, certain = match >= 0, match == MATCH_NEGATIVE, match != MATCH_UNCERTAIN
-            d = self.disc_loss(disc_logit[certain], pos[certain], return_dict=True)
+            offs = [tuple(x) for x in index_offsets.tolist()]       # (host tensor when the step pre-copied it: no sync)
+            if match is None:
+                match = self._match_all(boxes_reg, disc_logit, boxes_label, offs)      # HOST int64 [nt, nq]
+            dev = disc_logit.device
+            # the assignment lives on the host: turn its masks into index tensors there (async upload) instead of
+            # boolean-mask indexing on the device, which synchronises once per mask
+            up = lambda t: t.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else t
+            flat = match.flatten()
+            pos_i, neg_i, cert_i = (m.nonzero().flatten() for m in (flat >= 0, flat == MATCH_NEGATIVE, flat != MATCH_UNCERTAIN))
+            dflat = disc_logit.flatten()
+            n_pos = pos_i.numel()
+            d = self.disc_loss(dflat.index_select(0, up(cert_i)), up((flat[cert_i] >= 0)), return_dict=True)
             loss = loss + d.pop('total')
             log.update({f'instance-disc-{k}': v for k, v in d.items()})
-            n_pos = int(pos.sum())
             if n_pos > 0:
+                pos_d = up(pos_i)
                 with torch.no_grad():
-                    d = self.disc_loss(disc_logit[pos], True, return_dict=True, alpha=False)
+                    d = self.disc_loss(dflat.index_select(0, pos_d), True, return_dict=True, alpha=False)
                     d.pop('total')
                     log.update({f'instance-disc-pos-{k}': v for k, v in d.items()})
-                d = self.box_loss(boxes_reg[pos], boxes_label[match[pos]], return_dict=True)
+                d = self.box_loss(boxes_reg.reshape(-1, boxes_reg.shape[-1]).index_select(0, pos_d),
+                                  boxes_label.index_select(0, up(flat[pos_i])), return_dict=True)
                 loss = loss + d.pop('total')
                 log.update({f'instance-box-{k}': v for k, v in d.items()})
-            if n_pos < match.numel():
+            if n_pos < flat.numel():
                 with torch.no_grad():
-                    d = self.disc_loss(disc_logit[neg], False, return_dict=True, alpha=False)
+                    d = self.disc_loss(dflat.index_select(0, up(neg_i)), False, return_dict=True, alpha=False)
                     d.pop('total')
                     log.update({f'instance-disc-neg-{k}': v for k, v in d.items()})
         return loss, log
