@@ -6,6 +6,7 @@ libvividmed_hip.so; there is no eager/PyTorch fallback (a CPU tensor raises in m
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -81,6 +82,30 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
     return K.gemm(xdp, A0p, w1=A1p if gated else None, counts=counts if gated else None)
 
 
+_WGRAD_STREAMS: dict = {}
+WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
+
+
+def _off_critical_path(fn, device, keep_alive):
+    """Run `fn` (LoRA factor-gradient kernels that accumulate straight into the gradient buckets: nothing downstream in
+    backward reads their result) on a side stream. They are HBM-bound and their workgroups need little of a CU, so they fill
+    the tails of the MFMA-bound dgrad GEMMs on the main stream instead of serialising with them. The gradient bucket joins
+    the side stream before it is reduced / clipped (ddp._launch); `keep_alive` tensors are recorded on the side stream so
+    the caching allocator cannot hand their memory out while the kernels still read it."""
+    if not (WGRAD_SIDE_STREAM and device.type == 'cuda'):
+        fn()
+        return
+    side = _WGRAD_STREAMS.get(device)
+    if side is None:
+        side = _WGRAD_STREAMS[device] = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        fn()
+    for t in keep_alive:
+        if t is not None:
+            t.record_stream(side)
+
+
 def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
     """gradient of one LoRA factor through the skinny row-contraction kernel. When the parameter's gradient lives in a
     flat reduction bucket (ddp.BucketedGradAllReduce tags it with `_vm_grad_ready`) the kernel accumulates straight into
@@ -91,9 +116,11 @@ def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
         return K.gemm_tn(W, S, counts=counts, segment=seg, alpha=scale)
     ready = getattr(param, '_vm_grad_ready', None)
     if ready is not None and param.grad is not None and param.grad.dtype in (torch.bfloat16, torch.float32):
-        K.tn_skinny(W, S, transpose_out=transpose_out, out=param.grad, accumulate=True, counts=counts, segment=seg, alpha=scale,
-                    drop_p=drop_p, drop_seed=seed)
-        ready(param)
+        def run():
+            K.tn_skinny(W, S, transpose_out=transpose_out, out=param.grad, accumulate=True, counts=counts, segment=seg, alpha=scale,
+                        drop_p=drop_p, drop_seed=seed)
+            ready(param)
+        _off_critical_path(run, W.device, (W, S, counts))
         return None
     return K.tn_skinny(W, S, transpose_out=transpose_out, counts=counts, segment=seg, alpha=scale, drop_p=drop_p, drop_seed=seed,
                        out_dtype=param.dtype)
@@ -107,10 +134,12 @@ def _lora_wgrad_pair(params, W, S, transpose_out, counts, scale, drop_p, seed):
     direct = (r0 is not None and r1 is not None and p0.grad is not None and p1.grad is not None and p0.grad.dtype == p1.grad.dtype
               and p0.grad.dtype in (torch.bfloat16, torch.float32) and p0.grad.stride() == p1.grad.stride())
     if direct:
-        K.tn_skinny(W, S, transpose_out=transpose_out, out=(p0.grad, p1.grad), accumulate=True, counts=counts, segment=2, alpha=scale,
-                    drop_p=drop_p, drop_seed=seed)
-        r0(p0)
-        r1(p1)
+        def run():
+            K.tn_skinny(W, S, transpose_out=transpose_out, out=(p0.grad, p1.grad), accumulate=True, counts=counts, segment=2,
+                        alpha=scale, drop_p=drop_p, drop_seed=seed)
+            r0(p0)
+            r1(p1)
+        _off_critical_path(run, W.device, (W, S, counts))
         return None, None
     return K.tn_skinny(W, S, transpose_out=transpose_out, counts=counts, segment=2, alpha=scale, drop_p=drop_p, drop_seed=seed,
                        out_dtype=p0.dtype)

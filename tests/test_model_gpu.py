@@ -283,3 +283,35 @@ def test_true_width_layers_match_oracle(dev):
     assert len(worst) > 30
     bad = {k: v for k, v in worst.items() if v > 6e-2}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_side_stream_factor_gradients_match_main_stream(dev, lm):
+    """LoRA factor gradients written straight into the gradient buckets from a side stream (functional._off_critical_path)
+    must equal the single-stream result bit for bit (the kernels are deterministic; only the ordering discipline differs)"""
+    from mmmm_amd import functional as Fh
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    lm.train()
+    batch, _ = make_inputs(dev, seed=17)
+    trainable = [p for p in lm.parameters() if p.requires_grad]
+    ddp = BucketedGradAllReduce(trainable, world_size=1, bucket_bytes=1 << 20)
+    res = []
+    old = Fh.WGRAD_SIDE_STREAM
+    try:
+        for side in (False, True, True):
+            Fh.WGRAD_SIDE_STREAM = side
+            ddp.zero_grad()
+            out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
+            out.loss.backward()
+            ddp.finish()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None})
+    finally:
+        Fh.WGRAD_SIDE_STREAM = old
+        ddp.remove()
+        for p in lm.parameters():
+            p.grad = None
+    assert any('lora_A' in n for n in res[0])
+    for other in res[1:]:
+        assert other.keys() == res[0].keys()
+        for n in res[0]:
+            assert torch.equal(res[0][n], other[n]), n
