@@ -221,8 +221,21 @@ class _Linear(Function):
                 # fp32 islands / odd shapes: K-contiguous transposes feed the NT kernel
                 def tr(z):
                     return K.transpose_segment(z, counts, e) if gated else K.transpose(z, pad_to=64)
-                dyT = tr(dy) if (need[base] or (lora and need[base + 4])) else None
-                if need[base]:
+                # full fp32 weight gradient of an ungated, LoRA-free linear whose gradient lives in a reduction bucket (the
+                # unfrozen SAM / iSAM / vg_proj linears): W.grad += dy^T x through the GEMM's residual path, transposes
+                # included, on the side stream — off the critical path, no temporary, no AccumulateGrad add
+                wready = getattr(W, '_vm_grad_ready', None)
+                if (need[base] and not gated and not lora and wready is not None and W.grad is not None and W.grad.dtype == torch.float32
+                        and dy.dtype == torch.float32 and W.grad.is_contiguous() and W.grad.shape[1] % 4 == 0):
+                    def run(W=W, wready=wready):
+                        K.gemm(tr(dy), tr(x), residual=W.grad, out=W.grad)
+                        wready(W)
+                    _off_critical_path(run, dy.device, (dy, x))
+                    need_w = False
+                else:
+                    need_w = need[base]
+                dyT = tr(dy) if (need_w or (lora and need[base + 4])) else None
+                if need_w:
                     g[base] = K.gemm(dyT, tr(x))
                 if lora and need[base + 4]:
                     dB = K.gemm(dyT, tr(t))
@@ -237,7 +250,14 @@ class _Linear(Function):
                     ones = torch.ones(8, dyT.shape[1], dtype=dyT.dtype, device=dyT.device)
                     g[base + 2] = K.gemm(dyT, ones)[:, 0].to(b.dtype)
                 else:
-                    g[base + 2] = K.colsum(dy).to(b.dtype)
+                    bready = getattr(b, '_vm_grad_ready', None)
+                    if bready is not None and b.grad is not None and b.grad.dtype == torch.float32 and b.grad.is_contiguous():
+                        def run_b(b=b, bready=bready):
+                            K.colsum(dy, out=b.grad)          # atomically accumulated into the bucket slot
+                            bready(b)
+                        _off_critical_path(run_b, dy.device, (dy,))
+                    else:
+                        g[base + 2] = K.colsum(dy).to(b.dtype)
         return tuple(g)
 
 

@@ -125,9 +125,12 @@ def transpose_segment(x: torch.Tensor, counts: torch.Tensor, segment: int, pad_t
     return out
 
 
-def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
+def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[c] += sum_r x[r, c] (fp32 atomics); `out`: an existing fp32 accumulator (e.g. a bias gradient in its bucket)"""
     assert x.dim() == 2 and x.stride(1) == 1
-    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == x.shape[1]
     hip.call('vm_colsum', ptr(x), _ld(x), ptr(out), x.shape[0], x.shape[1], dtype_code(x.dtype), ptr(nrows), stream())
     return out
 

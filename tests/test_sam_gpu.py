@@ -95,6 +95,45 @@ def test_sam_and_isam_match_oracle(dev):
         assert rel(a.grad, b.grad) < 2e-4
 
 
+def test_sam_parameter_gradients_through_the_bucket_path_match_oracle(dev):
+    """Unfrozen SAM (README Stage 1): with a BucketedGradAllReduce attached, the fp32 weight / bias gradients are written by
+    the GEMM residual path and the column-sum kernel straight into the bucket views from a side stream
+    (functional._off_critical_path). They must equal the oracle's parameter gradients, and a second accumulation must add."""
+    from oracle import vividmed as O
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    sam, _ = _tiny_sams(dev)
+    sam.train()
+    g = torch.Generator().manual_seed(16)
+    images = [torch.rand(3, 8, 16, 32, generator=g), torch.rand(3, 4, 32, 16, generator=g)]
+    patch = [(4, 8, 8), (2, 8, 8)]
+    prompts = [torch.randn(2, 128, generator=g), torch.randn(3, 128, generator=g)]
+    trainable = [p for p in sam.parameters() if p.requires_grad]
+    ddp = BucketedGradAllReduce(trainable, world_size=1, bucket_bytes=1 << 20)
+    try:
+        ddp.zero_grad()
+        for _ in range(2):          # two micro-batches: the second pass must ACCUMULATE
+            masks = sam([x.to(dev) for x in images], patch, [p.to(dev) for p in prompts])
+            sum(m.square().mean() for m in masks).backward()
+        ddp.finish()
+        torch.cuda.synchronize()
+        sd = {f'sam.{k}': v.requires_grad_(v.is_floating_point()) for k, v in oracle_state(sam).items()}
+        ref = O.sam_forward(sd, _sam_cfg(False), 'sam', images, patch, prompts)
+        sum(m.square().mean() for m in ref).backward()
+        checked = 0
+        for name, p in sam.named_parameters():
+            gr = sd[f'sam.{name}'].grad
+            if not p.requires_grad or gr is None or gr.norm() < 1e-7:     # (k_proj.bias: softmax is shift-invariant, gradient == 0)
+                continue
+            assert p.grad is not None, name
+            assert rel(p.grad, 2 * gr) < 5e-4, (name, rel(p.grad, 2 * gr))
+            checked += 1
+        assert checked > 40
+    finally:
+        ddp.remove()
+        for p in sam.parameters():
+            p.grad = None
+
+
 def test_losses_match_oracle_and_hungarian_is_bit_exact(dev):
     from oracle import vividmed as O
     from mmmm_amd.models.loss import DiceFocalLoss
