@@ -225,11 +225,18 @@ __global__ __launch_bounds__(ROW_THREADS) void rope_k(
     T* p2 = p1 + half;
     auto a = ldv<T>(p1); auto b = ldv<T>(p2);
     typename Elem<T>::vec_t oa, ob;
+    // table holds cat(freqs, freqs): entry i and i+half are equal, but keep both lookups literal; 16-byte table loads
+    float c1v[V], s1v[V], c2v[V], s2v[V];
+#pragma unroll
+    for (int i4 = 0; i4 < V; i4 += 4) {
+      *reinterpret_cast<f32x4_t*>(c1v + i4) = *reinterpret_cast<const f32x4_t*>(cr + ch * V + i4);
+      *reinterpret_cast<f32x4_t*>(s1v + i4) = *reinterpret_cast<const f32x4_t*>(sr + ch * V + i4);
+      *reinterpret_cast<f32x4_t*>(c2v + i4) = *reinterpret_cast<const f32x4_t*>(cr + half + ch * V + i4);
+      *reinterpret_cast<f32x4_t*>(s2v + i4) = *reinterpret_cast<const f32x4_t*>(sr + half + ch * V + i4);
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      // table holds cat(freqs, freqs): entry i and i+half are equal, but keep both lookups literal
-      const float c1 = cr[ch * V + i], s1 = sr[ch * V + i];
-      const float c2 = cr[half + ch * V + i], s2 = sr[half + ch * V + i];
+      const float c1 = c1v[i], s1 = s1v[i], c2 = c2v[i], s2 = s2v[i];
       const float x1 = Elem<T>::ld(a[i]), x2 = Elem<T>::ld(b[i]);
       if (!inverse) {
         // out = x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
