@@ -7,12 +7,13 @@ but calling a kernel needs a gfx950 device, and a missing library raises immedia
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 import re
 
 import torch
 
-LIB_PATH = Path(__file__).resolve().parent / 'lib' / 'libvividmed_hip.so'
+LIB_PATH = Path(os.environ.get('VM_LIB_PATH') or Path(__file__).resolve().parent / 'lib' / 'libvividmed_hip.so')   # VM_LIB_PATH: A/B builds
 HEADER_PATH = Path(__file__).resolve().parents[1] / 'include' / 'vividmed_hip.h'
 
 VM_BF16, VM_F32 = 0, 1
