@@ -64,6 +64,8 @@ def build(verbose: bool = True) -> Path:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    for tmp in LIB_DIR.glob(LIB_PATH.name + '.*'):        # hipcc leaves its offload-bundle temporaries beside the output
+        tmp.unlink()
     if verbose:
         print(f'built {LIB_PATH} from {len(srcs)} sources')
     return LIB_PATH
