@@ -352,13 +352,46 @@ def f10_state_dict_adapters(R):
     torch.save(res, OUT / 'f10_adapters.pt')
 
 
+F11_CASES = [
+    dict(conv=[('Where is the <p>liver</p>?', 'The <p>liver</p> is here, no <np>tumor</np> found.')], n_img=49, inference=False, grounding=True,
+         bop_weight=5.0, max_seq_len=None),
+    dict(conv=[('Describe the image.', 'A chest radiograph with <p>cardiomegaly</p> and <p>pleural effusion</p>.'),
+               ('Is there <np>pneumothorax</np>?', 'No <np>pneumothorax</np>.')], n_img=196, inference=False, grounding=True, bop_weight=2.5,
+         max_seq_len=None),
+    dict(conv=[('What modality is this?', 'CT.')], n_img=16, inference=False, grounding=False, bop_weight=1.0, max_seq_len=None),
+    dict(conv=[('Find <p>the left kidney</p> and <p>the spleen</p> please', 'ok <p>the left kidney</p></p> done')], n_img=9, inference=False,
+         grounding=True, bop_weight=5.0, max_seq_len=24),
+    dict(conv=[('First question', 'first <p>answer</p>'), ('Second question about <p>the lesion</p>', '')], n_img=49, inference=True,
+         grounding=True, bop_weight=None, max_seq_len=None),
+]
+
+
+def f11_vlm_inputs(R):
+    """prepare_vlm_inputs / get_text_position_ids / _collate_fn padding (mmmm/data/utils.py:20-145, datamodule.py:20-39) driven
+    by oracle/fake_tokenizer.py"""
+    from .fake_tokenizer import FakeTokenizer
+    from torch.nn.utils.rnn import pad_sequence
+    U = ref_shims.load_data_utils()
+    import sys
+    ConvTurn = sys.modules['mmmm.data.defs'].ConvTurn
+    tok = FakeTokenizer()
+    outs = []
+    for c in F11_CASES:
+        inputs, text = U.prepare_vlm_inputs([ConvTurn(q, a) for q, a in c['conv']], tok, c['n_img'], inference=c['inference'],
+                                            grounding=c['grounding'], max_seq_len=c['max_seq_len'], bop_weight=c['bop_weight'])
+        outs.append(dict(inputs={k: v.clone() for k, v in inputs.items()}, text=text))
+    train = [o['inputs'] for o, c in zip(outs, F11_CASES) if not c['inference']]
+    padded = {k: pad_sequence([x[k] for x in train], batch_first=True, padding_value=-100 if k == 'labels' else 0) for k in train[0]}
+    torch.save(dict(cases=F11_CASES, outputs=outs, collated=padded), OUT / 'f11_vlm_inputs.pt')
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shims.load()
     only = os.environ.get('GOLDEN_ONLY')
-    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters):
+    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters, f11_vlm_inputs):
         if only and only not in fn.__name__:
             continue
         fn(R)

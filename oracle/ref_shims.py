@@ -413,3 +413,34 @@ def load() -> RefModules:
         utils=g['mmmm.utils'],
         config=g['mmmm.models.cogvlm.configuration_cogvlm'],
     )
+
+
+def load_data_utils():
+    """The reference's `mmmm/data/utils.py` (prepare_vlm_inputs, get_text_position_ids) imported under a private name,
+    with empty stand-ins for the I/O libraries its *other* functions use (monai MetaTensor / transforms, nibabel, luolib
+    helpers, the sentencepiece-backed tokenizer class). SURVEY §8f N1. Development container only."""
+    install()
+    import importlib.util
+    name = 'mmmm.data._ref_utils'
+    if name in sys.modules:
+        return sys.modules[name]
+    if not hasattr(sys.modules['monai.data'], 'MetaTensor'):
+        sys.modules['monai.data'].MetaTensor = object
+    for n in ('nibabel', 'monai.transforms'):
+        if n not in sys.modules:
+            _mod(n)
+    sys.modules['luolib.utils'].load_pt_zst = None
+    if 'luolib.utils.misc' not in sys.modules:
+        _mod('luolib.utils.misc', min_stem=None)
+    if 'mmmm.tokenizer' not in sys.modules or not hasattr(sys.modules['mmmm.tokenizer'], 'MMMMTokenizer'):
+        _mod('mmmm.tokenizer', MMMMTokenizer=object)
+    if 'mmmm.data.sparse' not in sys.modules:
+        _mod('mmmm.data.sparse', Sparse=object)
+    spec = importlib.util.spec_from_file_location(name, REF / 'mmmm/data/utils.py')
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = 'mmmm.data'
+    sys.modules[name] = mod
+    src = (REF / 'mmmm/data/utils.py').read_text()
+    # the two token-type constants live at the bottom of the file; the functions reference them as globals
+    exec(compile(src, str(REF / 'mmmm/data/utils.py'), 'exec'), mod.__dict__)
+    return mod
