@@ -205,9 +205,12 @@ def main():
     ap.add_argument('--checkpointing', default=os.environ.get('VM_CHECKPOINTING', 'hbm'), choices=['hbm', 'reference'],
                     help="'reference': recompute every transformer layer in backward (mmmm.py:232-233); 'hbm': keep the "
                          "activations of as many layers as the free HBM of this device holds (same results, less recompute)")
+    ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
+                    help="'flat': fused clip + AdamW kernel over the gradient buckets; 'torch': clip on the buckets + torch.optim.AdamW(fused)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true',
                     help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
+    ap.add_argument('--event-stride', type=int, default=4, help='bracket every n-th launch of the dominant kernel with HIP events')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     args = ap.parse_args()
 
@@ -232,7 +235,11 @@ def main():
     model, tok = build(w, device, args.depth_scale)
     trainable = [p for p in model.parameters() if p.requires_grad]
     ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist)
-    opt = torch.optim.AdamW(trainable, lr=5e-5, weight_decay=0.01, fused=True)
+    from mmmm_amd.optim import FlatAdamW
+    if args.optimizer == 'flat':       # gradient clip (1.0) + AdamW in one kernel per bucket (mmmm_amd/optim.py)
+        opt = FlatAdamW(ddp, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(trainable, lr=5e-5, weight_decay=0.01, fused=True)
     batch = make_batch(w, tok, args.batch, device, seed=rank)      # resident in HBM before timing
 
     def step():
@@ -240,7 +247,8 @@ def main():
         loss = model.training_step(batch)
         loss.backward()
         ddp.finish()
-        ddp.clip_grad_norm_(1.0)                      # gradient_clip_val 1 (conf/phase-vg/fit.yaml), on the flat buckets
+        if args.optimizer != 'flat':
+            ddp.clip_grad_norm_(1.0)                  # gradient_clip_val 1 (conf/phase-vg/fit.yaml), on the flat buckets
         opt.step()
         return loss
 
@@ -266,6 +274,7 @@ def main():
     use_events = not args.no_kernel_events
     if use_events:
         K.prof_reset()
+        K.prof_stride(args.event_stride)
         K.prof_enable(True if args.all_kernel_events else (hip.PROF_GEMM_BF16,))
     if use_dist:
         dist.barrier()
@@ -295,7 +304,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'optimizer': 'AdamW(fused) + clip 1.0', 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             'model_tflops_per_image': fl_sample / 1e12,
             'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,
@@ -313,8 +322,8 @@ def main():
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
                                'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_flops_per_launch': fl / max(n, 1),
-                               'launches': n, 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * 1e-3 / dt,
-                               'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over every launch of the timed region / summed HIP-event durations'}
+                               'launches': n, 'launch_sample': f'every {args.event_stride}th launch of the timed region', 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * args.event_stride * 1e-3 / dt,
+                               'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over the bracketed launches of the timed region / their summed HIP-event durations'}
             ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)
             if n_a:
                 out['attention'] = {'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12, 'launches': n_a, 'kernel_time_share': ms_a * 1e-3 / dt}

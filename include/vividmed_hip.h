@@ -54,6 +54,7 @@ int vm_device_arch(char* name_host, int len);
  * summed duration and the summed algorithmic FLOPs. */
 int vm_prof_enable(int kind_mask);   /* bit k set: bracket launches of kind VM_PROF_* == k; 0 disables */
 int vm_prof_reset(void);
+int vm_prof_stride(int every);        /* bracket every `every`-th launch of an enabled kind (uniform sample; default 1) */
 int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, int64_t* launches_host);
 /* algorithmic bytes (operands read once + result written once) summed by the last vm_prof_collect (GEMM kinds) */
 int vm_prof_last_bytes(double* bytes_host);
@@ -261,6 +262,13 @@ int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, in
  * out[c, i] = in[begin + i, c], zero beyond the segment. Feeds the per-expert LoRA weight gradients. */
 int vm_transpose_segment(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                          int rows, int cols, int dtype, const int32_t* counts_dev, int segment, void* stream);
+
+/* Fused gradient clip + AdamW over one flat bucket (the optimizer side of the step: conf/phase-vg/fit.yaml gradient_clip_val
+ * 1.0 + torch.optim.AdamW). p, g, m, v: n elements of `dtype` (n % 8 == 0 for bf16, % 4 for fp32, 16-byte
+ * aligned); maths in fp32. g is scaled by clip_coef_dev[0] (device scalar; NULL = 1) before it enters the moments.
+ * step >= 1 is the 1-based step count for the bias corrections. */
+int vm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, const float* clip_coef_dev, int dtype, void* stream);
 
 /* out_accum[c] += sum_r x[r, c] (fp32, atomically accumulated: zero it first). Bias gradients. */
 int vm_colsum(const void* x, int64_t ld, float* out_accum, int rows, int cols, int dtype,

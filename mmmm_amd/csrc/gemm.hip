@@ -266,6 +266,8 @@ struct ProfRec { hipEvent_t a, b; double flops; double bytes; };
 struct ProfState {
   std::mutex mu;
   unsigned mask = 0;       // bit k: bracket launches of kind k
+  int stride = 1;          // bracket every stride-th launch of a kind (uniform sample: 2 hipEventRecord per bracketed launch)
+  unsigned long long seen[4] = {0, 0, 0, 0};
   std::vector<ProfRec> recs[4];
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -279,6 +281,7 @@ extern "C" int vm_prof_begin_(int kind, void* stream, void** tok) {
   ProfState& s = prof();
   if (!((s.mask >> kind) & 1u)) { *tok = nullptr; return 0; }
   std::lock_guard<std::mutex> lk(s.mu);
+  if (s.seen[kind]++ % (unsigned long long)s.stride) { *tok = nullptr; return 0; }
   ProfRec r;
   if (!s.pool.empty()) { r.a = s.pool.back().first; r.b = s.pool.back().second; s.pool.pop_back(); }
   else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { *tok = nullptr; return 0; } }
@@ -320,6 +323,8 @@ int vm_prof_enable(int kind_mask) { prof().mask = (unsigned)kind_mask & 0xFu; re
 /* algorithmic operand + result bytes (A, B, extension operands read once, C written once) summed by the LAST
  * vm_prof_collect call (bf16 / fp32 GEMM kinds; 0 for the others) */
 int vm_prof_last_bytes(double* bytes_host) { if (!bytes_host) return VM_ERR_BAD_ARG; *bytes_host = prof_last_bytes(); return VM_OK; }
+
+int vm_prof_stride(int every) { if (every < 1) return VM_ERR_BAD_ARG; prof().stride = every; return VM_OK; }
 
 int vm_prof_reset(void) {
   ProfState& s = prof();

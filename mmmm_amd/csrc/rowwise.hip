@@ -449,6 +449,32 @@ __global__ __launch_bounds__(256) void transpose_batched_k(const int64_t* __rest
   }
 }
 
+// ---------------------------------------------------------------- fused gradient clip + AdamW over a flat bucket
+// One pass over a flat parameter / gradient / moment bucket (torch.optim.AdamW semantics, decoupled weight decay, maths in
+// fp32, states stored in the parameter dtype): g' = g * clip_coef[0] (device scalar: no host round trip for the norm),
+// p *= 1 - lr*wd; m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_k(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v,
+                                               int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                               float rsqrt_bc2, const float* __restrict__ clip_coef) {
+  constexpr int V = Elem<T>::VEC;
+  const float coef = clip_coef ? clip_coef[0] : 1.0f;
+  const float step = lr / bc1, decay = 1.0f - lr * wd;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (int64_t)gridDim.x * 256 * V) {
+    auto pv = ldv<T>(p + i); auto gv = ldv<T>(g + i); auto mv = ldv<T>(m + i); auto vv = ldv<T>(v + i);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float gg = Elem<T>::ld(gv[e]) * coef;
+      float pp = Elem<T>::ld(pv[e]) * decay;
+      const float mm = b1 * Elem<T>::ld(mv[e]) + (1.0f - b1) * gg;
+      const float ww = b2 * Elem<T>::ld(vv[e]) + (1.0f - b2) * gg * gg;
+      pp -= step * mm / (sqrtf(ww) * rsqrt_bc2 + eps);
+      pv[e] = Elem<T>::st(pp); mv[e] = Elem<T>::st(mm); vv[e] = Elem<T>::st(ww);
+    }
+    stv<T>(p + i, pv); stv<T>(m + i, mv); stv<T>(v + i, vv);
+  }
+}
+
 // ---------------------------------------------------------------- column sums (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
@@ -765,6 +791,20 @@ int vm_transpose_segment(const void* in, int64_t ld_in, void* out, int64_t ld_ou
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                            ld_in, (T*)out, ld_out, rows, cols, (const int32_t*)nullptr, counts_dev, segment));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int step, const float* clip_coef_dev, int dtype, void* stream) {
+  if (n <= 0) return VM_OK;
+  if (!p || !g || !m || !v || step < 1) return VM_ERR_BAD_ARG;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (n % vec || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return VM_ERR_BAD_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float rsqrt_bc2 = 1.0f / sqrtf(1.0f - powf(beta2, (float)step));
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_k<T>, dim3(ew_grid(n, vec)), dim3(256), 0, (hipStream_t)stream, (T*)p, (const T*)g,
+                                           (T*)m, (T*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, rsqrt_bc2, clip_coef_dev));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

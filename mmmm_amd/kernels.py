@@ -454,11 +454,25 @@ def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim,
     return dqkv
 
 
+def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+           weight_decay: float = 1e-2, step: int, clip_coef: torch.Tensor | None = None):
+    """in-place fused clip + AdamW over flat 1-D buffers of one dtype"""
+    assert p.dim() == 1 and p.is_contiguous() and g.shape == p.shape and m.shape == p.shape and v.shape == p.shape
+    assert g.dtype == p.dtype and m.dtype == p.dtype and v.dtype == p.dtype
+    assert clip_coef is None or (clip_coef.dtype == torch.float32 and clip_coef.numel() == 1)
+    hip.call('vm_adamw', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, ptr(clip_coef),
+             dtype_code(p.dtype), stream())
+
+
 # ------------------------------------------------------------------ profiling helpers
 def prof_enable(kinds=True):
     """kinds: True (every kind), False / () (off) or an iterable of hip.PROF_* kinds"""
     mask = 0xF if kinds is True else 0 if not kinds else sum(1 << int(k) for k in kinds)
     hip.call('vm_prof_enable', mask)
+
+
+def prof_stride(every: int):
+    hip.call('vm_prof_stride', int(every))
 
 
 def prof_reset():

@@ -555,3 +555,32 @@ def test_gemm_tn_segments_and_dropout(dev, K):
     Yd = K.dropout(Y, p, seed)
     got = K.gemm_tn(X, Y, counts=counts, segment=1, drop_p=p, drop_seed=seed)
     assert rel_err(got, X[200:M].float().T @ Yd[200:M].float()) < 4e-3
+
+
+# ------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_flat_adamw_with_clipping_matches_torch(dev, K, dt):
+    """FlatAdamW (vm_adamw over the gradient buckets, clip folded in) against clip_grad_norm_ + torch.optim.AdamW"""
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.optim import FlatAdamW
+    torch.manual_seed(0)
+    shapes = [(64, 96), (33,), (7, 5, 3), (128, 64)]
+    mine = [torch.nn.Parameter(torch.randn(s, device=dev).to(dt)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    ddp = BucketedGradAllReduce(mine, world_size=1, bucket_bytes=16384)
+    opt = FlatAdamW(ddp, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, max_grad_norm=1.0)
+    ropt = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, fused=True)
+    for it in range(4):
+        ddp.zero_grad()
+        grads = [torch.randn(s, device=dev).to(dt) * (3.0 if it % 2 == 0 else 0.01) for s in shapes]     # clipped / not clipped
+        for p, r, g in zip(mine, ref, grads):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        ddp.finish()
+        norm = opt.step()
+        rnorm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        assert rel_err(norm, rnorm) < (5e-3 if dt == torch.bfloat16 else 1e-5)        # torch returns the norm rounded to bf16
+        for p, r in zip(mine, ref):
+            assert rel_err(p, r) < (4e-3 if dt == torch.bfloat16 else 2e-6), it
+    ddp.remove()
