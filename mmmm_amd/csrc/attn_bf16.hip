@@ -3,13 +3,13 @@
 //   modeling_cogvlm.py:113-128  BlockDiagonalCausalMask, head_dim 128 (LM)
 //   visual.py:91-99             BlockDiagonalMask, head_dim 112 (EVA ViT)
 //
-// Layout trick (guide §3 "An accumulator tile as the next MFMA's operand"): scores are computed
-// TRANSPOSED, S^T[kv][q] = K·Q^T with v_mfma_f32_32x32x16_bf16, so that the query index sits on the
-// lane (col = lane&31) and a lane's 16 registers are 16 kv positions. Row max / sum are then in-lane
-// reductions plus one cross-half shuffle, and the bf16-converted registers are directly the B operand
-// of O^T[d][q] += V^T·P^T whose A operand (V^T) is fetched with ds_read_b64_tr_b16 from the row-major
-// V tile. O^T keeps the query on the lane too, so rescaling by the running max is a per-lane scalar.
-// The backward is two kernels of the same shape (dQ: query-stationary; dK/dV: key-stationary), no atomics.
+// Layout (guide §3 "An accumulator tile as the next MFMA's operand"): scores are computed TRANSPOSED,
+// S^T[kv][q] = K·Q^T with v_mfma_f32_16x16x32_bf16, so that the query index sits on the lane (col = lane & 15) and a
+// lane's registers are kv positions. Row max / sum are in-lane reductions plus two shuffles, and two stacked accumulator
+// tiles, converted to bf16, are directly the B operand of O^T[d][q] += V^T·P^T whose A operand (V^T) is fetched with
+// ds_read_b64_tr_b16 from the row-major V tile. O^T keeps the query on the lane too, so rescaling by the running max is a
+// per-lane scalar. A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV): ~110 VGPRs, 16 waves per CU.
+// The backward is delta + two kernels of the same shape (dQ: query-stationary; dK/dV: key-stationary), no atomics.
 #include "vm_common.hpp"
 #include "vm_tile.hpp"
 
@@ -50,164 +50,6 @@ __device__ __forceinline__ int phys_row(const AttnP& p, int gpos) {
   return p.row_of_pos ? p.row_of_pos[gpos] : gpos;
 }
 
-// Stage `nrows_tile` (64 or 32...) rows of a [pos][HD] operand into a swizzled LDS tile through registers.
-// Thread t handles chunks t, t+256, ...; rows past `n_valid` and columns past HD are zero.
-template <int HD, int ROWS>
-struct Stager {
-  static constexpr int CHUNKS = ROWS * 16;          // 16-byte chunks per tile
-  static constexpr int PER_T = CHUNKS / 256;
-  i32x4_t regs[PER_T];
-  __device__ __forceinline__ void load(const AttnP& p, const unsigned short* base, int64_t ld, int head,
-                                       int seq0, int pos0, int seqlen, int tid) {
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 4, chunk = c & 15;
-      const int pos = pos0 + row;
-      i32x4_t v = {0, 0, 0, 0};
-      if (pos < seqlen && chunk * 8 < HD) {
-        const int64_t r = phys_row(p, seq0 + pos);
-        v = *reinterpret_cast<const i32x4_t*>(base + r * ld + head * HD + chunk * 8);
-      }
-      regs[i] = v;
-    }
-  }
-  __device__ __forceinline__ void store(char* tile, int tid) const {
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 4, chunk = c & 15;
-      *reinterpret_cast<i32x4_t*>(tile + tile_off(row, chunk)) = regs[i];
-    }
-  }
-};
-
-// ----------------------------------------------------------------------------- forward
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_k(const AttnP p) {
-  constexpr int KD = HD / 16;          // k-steps of Q·K^T
-  constexpr int NB = (HD + 31) / 32;   // 32-wide d blocks of O
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * ROWB];
-  char* sK = smem;
-  char* sV = smem + 64 * ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z;
-  const int seq0 = p.cu[seq];
-  const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = blockIdx.x * 128;
-  if (q0 >= seqlen) return;
-  const int qpos = q0 + wave * 32 + (lane & 31);
-  const bool qvalid = qpos < seqlen;
-  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
-
-  // Q fragments (B operand of S^T = K·Q^T): lane holds Q[qpos][16s + 8h + 0..7]
-  bf16x8_t qf[KD];
-#pragma unroll
-  for (int s = 0; s < KD; ++s) {
-    i32x4_t v = {0, 0, 0, 0};
-    if (qvalid) v = *reinterpret_cast<const i32x4_t*>(p.q + qrow * p.ldq + head * HD + 16 * s + 8 * h);
-    qf[s] = __builtin_bit_cast(bf16x8_t, v);
-  }
-
-  f32x16_t o[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
-  const float sc = p.scale * LOG2E;
-
-  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
-  const int nt = (kv_end + 63) / 64;
-  Stager<HD, 64> stK, stV;
-  stK.load(p, p.k, p.ldk, head, seq0, 0, seqlen, tid);
-  stV.load(p, p.v, p.ldv, head, seq0, 0, seqlen, tid);
-  stK.store(sK, tid); stV.store(sV, tid);
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int kv0 = t * 64;
-    if (t + 1 < nt) {
-      stK.load(p, p.k, p.ldk, head, seq0, kv0 + 64, seqlen, tid);
-      stV.load(p, p.v, p.ldv, head, seq0, kv0 + 64, seqlen, tid);
-    }
-    // S^T tiles: [2][32 kv x 32 q]
-    f32x16_t sacc[2];
-#pragma unroll
-    for (int t32 = 0; t32 < 2; ++t32) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[t32][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < KD; ++s)
-        sacc[t32] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, 32 * t32, s, lane), qf[s], sacc[t32], 0, 0, 0);
-    }
-    // scale + mask + online softmax (query on the lane)
-    float mx = NEG_BIG;
-    const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;  // last visible kv position
-#pragma unroll
-    for (int t32 = 0; t32 < 2; ++t32)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kvpos = kv0 + 32 * t32 + acc_row(r, h);
-        float x = sacc[t32][r] * sc;
-        x = kvpos <= lim ? x : NEG_BIG;
-        sacc[t32][r] = x;
-        mx = fmaxf(mx, x);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int t32 = 0; t32 < 2; ++t32)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(sacc[t32][r] - m_new);
-        sacc[t32][r] = e;
-        rs += e;
-      }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
-    // O^T[d][q] += V^T · P^T
-#pragma unroll
-    for (int t32 = 0; t32 < 2; ++t32)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8_t pf = pack8(sacc[t32], s);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sV, 32 * t32 + 16 * s, b, lane), pf, o[b], 0, 0, 0);
-      }
-    __syncthreads();
-    if (t + 1 < nt) {
-      stK.store(sK, tid); stV.store(sV, tid);
-      __syncthreads();
-    }
-  }
-
-  if (!qvalid) return;
-  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
-  if (h == 0 && p.lse) p.lse[(int64_t)head * p.total_pos_max + seq0 + qpos] = (m_run + log2f(l_run)) * LN2;
-  unsigned short* orow = p.out + qrow * p.ldo + head * HD;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = 32 * b + 8 * g + 4 * h;
-      if (d < HD) {
-        u16x4_t w = {f2bf(o[b][4 * g + 0] * inv_l), f2bf(o[b][4 * g + 1] * inv_l),
-                     f2bf(o[b][4 * g + 2] * inv_l), f2bf(o[b][4 * g + 3] * inv_l)};
-        *reinterpret_cast<u16x4_t*>(orow + d) = w;
-      }
-    }
-}
-
 // ----------------------------------------------------------------------------- delta = rowsum(dO * O)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_delta_k(const AttnP p, int n_seq) {
@@ -242,228 +84,10 @@ __global__ __launch_bounds__(256) void attn_delta_k(const AttnP p, int n_seq) {
   }
 }
 
-// ----------------------------------------------------------------------------- backward: dQ (query-stationary)
-template <int HD>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_k(const AttnP p) {
-  constexpr int KD = HD / 16;
-  constexpr int NB = (HD + 31) / 32;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * ROWB];
-  char* sK = smem;
-  char* sV = smem + 64 * ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z;
-  const int seq0 = p.cu[seq];
-  const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = blockIdx.x * 128;
-  if (q0 >= seqlen) return;
-  const int qpos = q0 + wave * 32 + (lane & 31);
-  const bool qvalid = qpos < seqlen;
-  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
-
-  bf16x8_t qf[KD], dof[KD];
-#pragma unroll
-  for (int s = 0; s < KD; ++s) {
-    i32x4_t a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (qvalid) {
-      a = *reinterpret_cast<const i32x4_t*>(p.q + qrow * p.ldq + head * HD + 16 * s + 8 * h);
-      b = *reinterpret_cast<const i32x4_t*>(p.dout + qrow * p.lddo + head * HD + 16 * s + 8 * h);
-    }
-    qf[s] = __builtin_bit_cast(bf16x8_t, a);
-    dof[s] = __builtin_bit_cast(bf16x8_t, b);
-  }
-  const float lse2 = qvalid ? p.lse[(int64_t)head * p.total_pos_max + seq0 + qpos] * LOG2E : 0.f;
-  const float dlt = qvalid ? p.delta[(int64_t)head * p.total_pos_max + seq0 + qpos] : 0.f;
-  const float sc = p.scale * LOG2E;
-
-  f32x16_t dq[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
-
-  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
-  const int nt = (kv_end + 63) / 64;
-  Stager<HD, 64> stK, stV;
-  stK.load(p, p.k, p.ldk, head, seq0, 0, seqlen, tid);
-  stV.load(p, p.v, p.ldv, head, seq0, 0, seqlen, tid);
-  stK.store(sK, tid); stV.store(sV, tid);
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int kv0 = t * 64;
-    if (t + 1 < nt) {
-      stK.load(p, p.k, p.ldk, head, seq0, kv0 + 64, seqlen, tid);
-      stV.load(p, p.v, p.ldv, head, seq0, kv0 + 64, seqlen, tid);
-    }
-    const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
-#pragma unroll
-    for (int t32 = 0; t32 < 2; ++t32) {
-      f32x16_t sa, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < KD; ++s) {
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, 32 * t32, s, lane), qf[s], sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, 32 * t32, s, lane), dof[s], dp, 0, 0, 0);
-      }
-      // dS^T = P ∘ (dP^T − delta) · scale
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kvpos = kv0 + 32 * t32 + acc_row(r, h);
-        const float pr = (kvpos <= lim && qvalid) ? exp2f(sa[r] * sc - lse2) : 0.f;
-        sa[r] = pr * (dp[r] - dlt) * p.scale;
-      }
-      // dQ^T[d][q] += K^T · dS^T
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8_t df = pack8(sa, s);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          dq[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sK, 32 * t32 + 16 * s, b, lane), df, dq[b], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (t + 1 < nt) {
-      stK.store(sK, tid); stV.store(sV, tid);
-      __syncthreads();
-    }
-  }
-  if (!qvalid) return;
-  unsigned short* drow = p.dq + qrow * p.lddq + head * HD;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = 32 * b + 8 * g + 4 * h;
-      if (d < HD) {
-        u16x4_t w = {f2bf(dq[b][4 * g + 0]), f2bf(dq[b][4 * g + 1]), f2bf(dq[b][4 * g + 2]), f2bf(dq[b][4 * g + 3])};
-        *reinterpret_cast<u16x4_t*>(drow + d) = w;
-      }
-    }
-}
-
-// ----------------------------------------------------------------------------- backward: dK, dV (key-stationary)
-// Mirror image: the key index sits on the lane. S[q][kv] = Q·K^T with Q row-read from LDS and K in
-// registers; dV^T[d][kv] += dO^T·P and dK^T[d][kv] += Q^T·dS use transposed reads of the dO / Q tiles.
-template <int HD>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_k(const AttnP p) {
-  constexpr int KD = HD / 16;
-  constexpr int NB = (HD + 31) / 32;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * ROWB + 2 * 32 * 4];
-  char* sQ = smem;
-  char* sDO = smem + 32 * ROWB;
-  float* sLse = reinterpret_cast<float*>(smem + 2 * 32 * ROWB);
-  float* sDlt = sLse + 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z;
-  const int seq0 = p.cu[seq];
-  const int seqlen = p.cu[seq + 1] - seq0;
-  const int k0 = blockIdx.x * 128;
-  if (k0 >= seqlen) return;
-  const int kpos = k0 + wave * 32 + (lane & 31);
-  const bool kvalid = kpos < seqlen;
-  const int64_t krow = kvalid ? phys_row(p, seq0 + kpos) : 0;
-
-  bf16x8_t kf[KD], vf[KD];
-#pragma unroll
-  for (int s = 0; s < KD; ++s) {
-    i32x4_t a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (kvalid) {
-      a = *reinterpret_cast<const i32x4_t*>(p.k + krow * p.ldk + head * HD + 16 * s + 8 * h);
-      b = *reinterpret_cast<const i32x4_t*>(p.v + krow * p.ldv + head * HD + 16 * s + 8 * h);
-    }
-    kf[s] = __builtin_bit_cast(bf16x8_t, a);
-    vf[s] = __builtin_bit_cast(bf16x8_t, b);
-  }
-  const float sc = p.scale * LOG2E;
-  f32x16_t dk[NB], dv[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
-
-  const int q_begin = p.causal ? (k0 / 32) * 32 : 0;   // queries before the key block see none of it
-  const int nt = (seqlen - q_begin + 31) / 32;
-  Stager<HD, 32> stQ, stDO;
-  float lse_r = 0.f, dlt_r = 0.f;
-  auto load_stats = [&](int qq0) {
-    if (tid < 32) {
-      const int qp = qq0 + tid;
-      lse_r = qp < seqlen ? p.lse[(int64_t)head * p.total_pos_max + seq0 + qp] * LOG2E : 0.f;
-      dlt_r = qp < seqlen ? p.delta[(int64_t)head * p.total_pos_max + seq0 + qp] : 0.f;
-    }
-  };
-  auto store_stats = [&]() { if (tid < 32) { sLse[tid] = lse_r; sDlt[tid] = dlt_r; } };
-  stQ.load(p, p.q, p.ldq, head, seq0, q_begin, seqlen, tid);
-  stDO.load(p, p.dout, p.lddo, head, seq0, q_begin, seqlen, tid);
-  load_stats(q_begin);
-  stQ.store(sQ, tid); stDO.store(sDO, tid); store_stats();
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int qq0 = q_begin + t * 32;
-    if (t + 1 < nt) {
-      stQ.load(p, p.q, p.ldq, head, seq0, qq0 + 32, seqlen, tid);
-      stDO.load(p, p.dout, p.lddo, head, seq0, qq0 + 32, seqlen, tid);
-      load_stats(qq0 + 32);
-    }
-    f32x16_t sa, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < KD; ++s) {
-      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, 0, s, lane), kf[s], sa, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sDO, 0, s, lane), vf[s], dp, 0, 0, 0);
-    }
-    f32x16_t pa;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = acc_row(r, h);
-      const int qp = qq0 + qi;
-      const bool vis = kvalid && qp < seqlen && (!p.causal || kpos <= qp);
-      const float pr = vis ? exp2f(sa[r] * sc - sLse[qi]) : 0.f;
-      pa[r] = pr;
-      sa[r] = pr * (dp[r] - sDlt[qi]) * p.scale;
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8_t pf = pack8(pa, s);
-      const bf16x8_t df = pack8(sa, s);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        dv[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sDO, 16 * s, b, lane), pf, dv[b], 0, 0, 0);
-        dk[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sQ, 16 * s, b, lane), df, dk[b], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (t + 1 < nt) {
-      stQ.store(sQ, tid); stDO.store(sDO, tid); store_stats();
-      __syncthreads();
-    }
-  }
-  if (!kvalid) return;
-  unsigned short* dkrow = p.dk + krow * p.lddk + head * HD;
-  unsigned short* dvrow = p.dv + krow * p.lddv + head * HD;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = 32 * b + 8 * g + 4 * h;
-      if (d < HD) {
-        u16x4_t wk = {f2bf(dk[b][4 * g + 0]), f2bf(dk[b][4 * g + 1]), f2bf(dk[b][4 * g + 2]), f2bf(dk[b][4 * g + 3])};
-        u16x4_t wv = {f2bf(dv[b][4 * g + 0]), f2bf(dv[b][4 * g + 1]), f2bf(dv[b][4 * g + 2]), f2bf(dv[b][4 * g + 3])};
-        *reinterpret_cast<u16x4_t*>(dkrow + d) = wk;
-        *reinterpret_cast<u16x4_t*>(dvrow + d) = wv;
-      }
-    }
-}
-
 // =====================================================================================================================
-// 16-wide kernels (production path). A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV) and works with
-// v_mfma_f32_16x16x32_bf16, so its register footprint is about half that of the 32-wide kernels above: 16 waves per CU
-// instead of 4-8, and the MFMA, VALU (softmax) and LDS phases of different waves overlap by thread-level parallelism.
+// A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV) and works with v_mfma_f32_16x16x32_bf16: half the register
+// footprint of a 32-wide design (the first generation of these kernels: 4-8 waves per CU, 2.3x slower), 16 waves per CU,
+// and the MFMA, VALU (softmax) and LDS phases of different waves overlap by thread-level parallelism.
 // Operand tiles are staged by LDS-DMA (buffer_load ... lds, swizzle applied to the source chunk) into a 2-stage ring,
 // one barrier per 64-position tile; the tile after next's physical rows (packed-layout indirection) are fetched one
 // iteration ahead. Score tiles are kept transposed (key on the MFMA row, query on the lane) exactly as above.
@@ -941,12 +565,6 @@ bool args_ok(const vm_attn_args* a) {
   return true;
 }
 
-// VM_ATTN_IMPL=32 selects the 32-wide kernels (A/B measurements); default: 16-wide
-int attn_impl() {
-  static int impl = -1;
-  if (impl < 0) { const char* e = getenv("VM_ATTN_IMPL"); impl = (e && atoi(e) == 32) ? 32 : 16; }
-  return impl;
-}
 // dynamic LDS above 64 KiB needs the attribute once per kernel
 bool lds_ok(const void* fn, int bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
@@ -992,13 +610,9 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  if (attn_impl() == 32) {
-    ATTN_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
-  } else {
     ATTN_DISPATCH_HD(a->head_dim,
                      if (!lds_ok((const void*)attn16_fwd_k<HD>, A16_LDS)) return VM_ERR_LAUNCH;
                      hipLaunchKernelGGL(attn16_fwd_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p));
-  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
   VM_LAUNCH_CHECK();
   return VM_OK;
@@ -1013,20 +627,12 @@ int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  if (attn_impl() == 32) {
-    ATTN_DISPATCH_HD(a->head_dim,
-                     hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                                        (hipStream_t)stream, p, a->n_seq);
-                     hipLaunchKernelGGL(attn_bwd_dq_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p);
-                     hipLaunchKernelGGL(attn_bwd_dkv_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
-  } else {
     ATTN_DISPATCH_HD(a->head_dim,
                      if (!lds_ok((const void*)attn16_dq_k<HD>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
                      hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
                                         (hipStream_t)stream, p, a->n_seq);
                      hipLaunchKernelGGL(attn16_dq_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p);
                      hipLaunchKernelGGL(attn16_dkv_k<HD>, grid16(a), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
-  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
   VM_LAUNCH_CHECK();
   return VM_OK;
