@@ -169,7 +169,9 @@ int vm_gemm_f32(const vm_gemm_args* args_host, void* stream);
 int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd,
                    int rows, int cols, float eps, int dtype,
                    const int32_t* nrows_dev, void* stream);
-/* dx = d/dx ; dw_partial is an fp32 [cols] accumulator (atomically added to, must be zeroed by the caller) */
+/* dx = d/dx ; dw_accum is an fp32 [cols] accumulator that is atomically ADDED to (a zeroed scratch or an fp32 gradient
+ * slot). dx == NULL skips the input gradient, dw_accum == NULL the weight gradient: the two halves may run on different
+ * streams (the parameter gradient is off the critical path of backward). Same for vm_layernorm_bwd. */
 int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd,
                    void* dx, float* dw_accum,
                    int rows, int cols, int dtype,

@@ -625,8 +625,8 @@ int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rs
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                    (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev);
+                 if (dx) hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                                            (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev);
                  if (dw_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                                   (const T*)dy, (const float*)nullptr, rstd, dw_accum, (float*)nullptr, rows, cols,
                                                   nrows_dev));
@@ -655,8 +655,8 @@ int vm_layernorm_bwd(const void* x, const void* w, const void* dy, const float* 
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                    (const T*)dy, mean, rstd, (T*)dx, rows, cols);
+                 if (dx) hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
+                                            (const T*)dy, mean, rstd, (T*)dx, rows, cols);
                  if (dw_accum || db_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream,
                                                               (const T*)x, (const T*)dy, mean, rstd, dw_accum, db_accum, rows, cols,
                                                               (const int32_t*)nullptr));

@@ -268,6 +268,27 @@ def linear(x, W0, *, meta: LinearMeta | None = None, Wt0=None, b0=None, A0=None,
 
 
 # ----------------------------------------------------------------------------- norms
+def _norm_params_off_path(params, run_kernel, keep_alive):
+    """Weight / bias gradients of a norm layer, when their slots live in a gradient bucket: computed on the side stream and
+    added straight into the slots (fp32 slots: the kernel's atomics land there; bf16 slots: fp32 scratch, rounded, added —
+    the same rounding as AccumulateGrad would apply). Returns True when it took care of them."""
+    ps = [p for p in params if p is not None]
+    if not ps or any(getattr(p, '_vm_grad_ready', None) is None or p.grad is None or not p.grad.is_contiguous() for p in ps):
+        return False
+
+    def run():
+        if all(p.grad.dtype == torch.float32 for p in ps):
+            run_kernel(*[p.grad for p in ps])
+        else:
+            outs = run_kernel(*[None for _ in ps])
+            for p, g in zip(ps, outs):
+                p.grad.add_(g.to(p.grad.dtype))
+        for p in ps:
+            p._vm_grad_ready(p)
+    _off_critical_path(run, ps[0].device, keep_alive)
+    return True
+
+
 class _RMSNorm(Function):
     @staticmethod
     def forward(ctx, x, w, eps, nrows):
@@ -279,6 +300,9 @@ class _RMSNorm(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, w, rstd, nrows = ctx.saved_tensors
+        if ctx.needs_input_grad[1] and _norm_params_off_path(
+                (w,), lambda dw_out: (K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dx=False, dw_out=dw_out)[1],), (x, dy, rstd, nrows)):
+            return K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=False)[0], None, None, None
         dx, dw = K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=ctx.needs_input_grad[1])
         return dx, (dw.to(w.dtype) if dw is not None else None), None, None
 
@@ -293,6 +317,7 @@ class _LayerNorm(Function):
         y, mean, rstd = K.layernorm_fwd(x, w, b, eps, residual)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.has_res = residual is not None
+        ctx.bias = b          # only its gradient slot is touched in backward (no value needed): not saved as a tensor
         return y
 
     @staticmethod
@@ -300,6 +325,11 @@ class _LayerNorm(Function):
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
         need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        b = ctx.bias
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and b is not None and _norm_params_off_path(
+                (w, b), lambda dw_out, db_out: K.layernorm_bwd(x, w, dy, mean, rstd, need_dx=False, dw_out=dw_out, db_out=db_out)[1:],
+                (x, dy, mean, rstd)):
+            return K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=False)[0], None, None, None, (dy if ctx.has_res else None)
         dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=need_dw)
         return (dx, dw.to(w.dtype) if dw is not None else None, db.to(w.dtype) if db is not None else None, None,
                 dy if ctx.has_res else None)

@@ -292,6 +292,7 @@ def test_side_stream_factor_gradients_match_main_stream(dev, lm):
     from mmmm_amd.ddp import BucketedGradAllReduce
     lm.train()
     batch, _ = make_inputs(dev, seed=17)
+    plain = _grads(lm, batch)[1]          # no buckets: every gradient goes through autograd's AccumulateGrad
     trainable = [p for p in lm.parameters() if p.requires_grad]
     ddp = BucketedGradAllReduce(trainable, world_size=1, bucket_bytes=1 << 20)
     res = []
@@ -311,6 +312,10 @@ def test_side_stream_factor_gradients_match_main_stream(dev, lm):
         for p in lm.parameters():
             p.grad = None
     assert any('lora_A' in n for n in res[0])
+    # bucket path (direct accumulation: LoRA factors, norm weights / biases) vs the plain autograd path
+    assert plain.keys() == res[0].keys()
+    for n in plain:
+        assert rel(res[0][n].float(), plain[n].float()) < 2e-3, (n, rel(res[0][n].float(), plain[n].float()))
     for other in res[1:]:
         assert other.keys() == res[0].keys()
         for n in res[0]:
