@@ -39,11 +39,17 @@ WORKLOADS = {
                           desc='phase-vlm (sam=None) LoRA bf16, 2D 448x448, batch 8/GPU, CogVLM-7B'),
     'phase-grg-3d': dict(image=(3, 32, 256, 256), patch=(4, 16, 16), pool=(2, 2, 2), text=256, sam=True,
                          desc='BASELINE configs[3]: phase-grg 3D CT 32x256x256'),
+    # BASELINE configs[2]: per-rank batch = half 2D 448x448, half 3D 32x256x256, variable text length, sam=None
+    'phase-vlm-mixed': dict(image=(3, 1, 448, 448), patch=(1, 16, 16), pool=(1, 2, 2), text=256, sam=False, mixed=True,
+                            desc='BASELINE configs[2]: phase-vlm, mixed 2D 448x448 / 3D 32x256x256 batch, text 128..512, CogVLM-7B'),
 }
 
 
 def train_flops_per_sample(w: dict, cfg, sam: bool) -> float:
     """algorithmic training FLOPs per sample, recompute excluded (SURVEY.md §8d formulas)"""
+    if w.get('mixed'):
+        a = {k: v for k, v in w.items() if k != 'mixed'}
+        return 0.5 * (train_flops_per_sample(a, cfg, sam) + train_flops_per_sample(WORKLOADS['phase-grg-3d'], cfg, sam))
     vc = cfg.vision_config
     d, f, h, i = vc['hidden_size'], vc['intermediate_size'], cfg.hidden_size, cfg.intermediate_size
     img, patch, pool = w['image'], w['patch'], w['pool']
@@ -120,6 +126,13 @@ def build(workload: dict, device, depth_scale: float = 1.0):
 def make_batch(workload: dict, tok, B: int, device, seed: int):
     from mmmm_amd.data.synthetic import make_batch as mk
     inst = [(i % 2 == 1) for i in range(B)] if workload['sam'] else [False] * B
+    if workload.get('mixed'):
+        w3 = WORKLOADS['phase-grg-3d']
+        g = torch.Generator().manual_seed(1000 + seed)
+        texts = torch.randint(128, 513, (B,), generator=g).tolist()
+        sel = [w3 if i % 2 else workload for i in range(B)]
+        return mk([w['image'] for w in sel], [w['patch'] for w in sel], [w['pool'] for w in sel], texts, tok=tok, seed=seed,
+                  grounding=False, n_pairs=4, instance=inst, device=device)
     return mk([workload['image']] * B, [workload['patch']] * B, [workload['pool']] * B, [workload['text']] * B, tok=tok,
               seed=seed, grounding=workload['sam'], n_pairs=4, instance=inst, device=device)
 
