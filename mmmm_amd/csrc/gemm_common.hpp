@@ -3,7 +3,10 @@
 #include "vm_common.hpp"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-constexpr int GROUP_M = 8;
+#ifndef VM_GROUP_M
+#define VM_GROUP_M 8
+#endif
+constexpr int GROUP_M = VM_GROUP_M;
 
 struct GemmParams {
   const char* A; int64_t lda;          // leading dimensions in ELEMENTS
