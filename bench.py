@@ -223,7 +223,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true',
                     help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
-    ap.add_argument('--event-stride', type=int, default=4, help='bracket every n-th launch of the dominant kernel with HIP events')
+    ap.add_argument('--event-stride', type=int, default=4, help='bracket a pseudo-random 1-in-n sample of the launches of the dominant kernel with HIP events')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     args = ap.parse_args()
 
@@ -335,7 +335,7 @@ def main():
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
                                'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_flops_per_launch': fl / max(n, 1),
-                               'launches': n, 'launch_sample': f'every {args.event_stride}th launch of the timed region', 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * args.event_stride * 1e-3 / dt,
+                               'launches': n, 'launch_sample': f'pseudo-random 1 in {args.event_stride} launches of the timed region', 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * args.event_stride * 1e-3 / dt,
                                'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over the bracketed launches of the timed region / their summed HIP-event durations'}
             ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)
             if n_a:

@@ -281,7 +281,8 @@ extern "C" int vm_prof_begin_(int kind, void* stream, void** tok) {
   ProfState& s = prof();
   if (!((s.mask >> kind) & 1u)) { *tok = nullptr; return 0; }
   std::lock_guard<std::mutex> lk(s.mu);
-  if (s.seen[kind]++ % (unsigned long long)s.stride) { *tok = nullptr; return 0; }
+  // pseudo-random 1-in-stride sample (a fixed period would alias with the per-layer launch pattern)
+  if (s.stride > 1 && ((unsigned)(s.seen[kind]++ * 2654435761ull >> 13) % (unsigned)s.stride)) { *tok = nullptr; return 0; }
   ProfRec r;
   if (!s.pool.empty()) { r.a = s.pool.back().first; r.b = s.pool.back().second; s.pool.pop_back(); }
   else { if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { *tok = nullptr; return 0; } }
