@@ -48,6 +48,65 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_b
 #define POST_MMA_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
 
+// epilogue shared by the two 256x256 kernels: accumulators -> (bias, residual) -> C. Every wave must have passed its last
+// LDS read (the staging memory is reused for the per-wave output slabs).
+template <bool OUT_F32>
+__device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[8][4], char* smem, int wave, int lane, int wm, int wn,
+                                            int row0, int nrows, int n0, int ncols, int seg) {
+  const int frow = lane & 15, fq = lane >> 4;
+  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
+  const void* bias = seg ? p.bias1 : p.bias0;
+  if (OUT_F32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wm * 128 + i * 16 + frow;
+      if (ml >= nrows) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + fq * 4;
+        if (nl >= ncols) continue;
+        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+      }
+    }
+  } else {
+    // every wave has passed the final barrier: LDS is free. 64 x 64 slab per wave, two passes (upper / lower 64 rows).
+    typedef EpiSlab<64, 64> Slab;
+    char* slab = smem + wave * Slab::BYTES;
+    const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
+    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
+    f32x4_t bv[4];
+    if (fast_bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = epi_bias4(bias, n0 + wn * 64 + j * 16 + fq * 4);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (fast_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j], bv[j]);
+      } else if (plain) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + fq * 4;
+            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
+          }
+      }
+      epi_flush<64, 64>(slab, p, row0 + wm * 128 + half * 64, n0 + wn * 64, nrows - wm * 128 - half * 64, ncols - wn * 64, lane);
+    }
+  }
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,57 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #endif
 
-  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
-  const void* bias = seg ? p.bias1 : p.bias0;
-  if (OUT_F32) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ml = wm * 128 + i * 16 + frow;
-      if (ml >= nrows) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nl = wn * 64 + j * 16 + fq * 4;
-        if (nl >= ncols) continue;
-        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
-      }
-    }
-  } else {
-    // every wave has passed the final barrier: LDS is free. 64 x 64 slab per wave, two passes (upper / lower 64 rows).
-    typedef EpiSlab<64, 64> Slab;
-    char* slab = smem + wave * Slab::BYTES;
-    const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
-    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
-    f32x4_t bv[4];
-    if (fast_bias) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = epi_bias4(bias, n0 + wn * 64 + j * 16 + fq * 4);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (fast_bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j], bv[j]);
-      } else if (plain) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int nl = wn * 64 + j * 16 + fq * 4;
-            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
-          }
-      }
-      epi_flush<64, 64>(slab, p, row0 + wm * 128 + half * 64, n0 + wn * 64, nrows - wm * 128 - half * 64, ncols - wn * 64, lane);
-    }
-  }
+  epilogue256<OUT_F32>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
 }
 
 }  // namespace
