@@ -78,15 +78,36 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return t;
 }
 
-// Counter-based RNG for dropout masks: one splitmix64 hash serves FOUR consecutive elements (16 bits each), so a
-// lane that owns 4 or 8 consecutive elements hashes once or twice. keep(idx) is a pure function of (seed, idx, p):
-// the standalone dropout kernel, the LoRA down-projection, the GEMM dgrad epilogue and the TN weight-gradient
-// kernel all regenerate the same mask (forward, checkpoint recompute and backward agree).
-__device__ __forceinline__ uint64_t vm_hash4(uint64_t seed, uint64_t group) {
-  uint64_t z = seed + (group + 1) * 0x9E3779B97F4A7C15ull;
+// Counter-based RNG for dropout masks: one hash serves FOUR consecutive elements (16 bits each), so a lane that owns 4
+// or 8 consecutive elements hashes once or twice. keep(idx) is a pure function of (seed, idx, p): the standalone dropout
+// kernel, the LoRA down-projection, the GEMM dgrad epilogue and the TN weight-gradient kernel all regenerate the same
+// mask (forward, checkpoint recompute and backward agree).
+// The per-element part is two 32-bit multiply-xorshift mixers (4 v_mul_lo_u32 per group of four elements). The seed goes
+// through splitmix64 on the scalar unit (it is wave-uniform) and its four words are injected before and between the two
+// rounds of each mixer, so masks of different seeds are not index permutations of one another
+// (tests/test_kernels_gpu.py::test_dropout_mask_independence). Measured: the masked extension costs a 256x256 GEMM tile
+// ~40 VALU instructions per four accumulators (index, hash, 4 x extract / compare / select / scale), +25 us on a
+// [6280 x 15360] dgrad; the multiplies are not what bounds it (a 64-bit splitmix per group timed the same).
+__device__ __forceinline__ uint64_t vm_splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned vm_mix32(unsigned x, unsigned s_in, unsigned s_mid) {
+  x ^= s_in;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= s_mid;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  return x ^ (x >> 16);
+}
+__device__ __forceinline__ uint64_t vm_hash4(uint64_t seed, uint64_t group) {
+  const uint64_t sa = vm_splitmix64(seed), sb = vm_splitmix64(seed ^ 0xD1B54A32D192ED03ull);
+  const unsigned hi = (unsigned)(group >> 32);
+  const unsigned k = (unsigned)group ^ (hi << 17) ^ (hi >> 3) ^ (hi * 0x9E3779B9u);       // hi == 0 below 2^34 elements
+  const unsigned a = vm_mix32(k, (unsigned)sa, (unsigned)(sa >> 32));
+  const unsigned b = vm_mix32(k, (unsigned)sb, (unsigned)(sb >> 32));
+  return (uint64_t)a | ((uint64_t)b << 32);
 }
 __device__ __forceinline__ unsigned vm_drop_threshold(float p) { return (unsigned)(p * 65536.0f); }
 __device__ __forceinline__ bool vm_keep_bits(uint64_t h, int sub, unsigned thr) {

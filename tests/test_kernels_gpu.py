@@ -282,6 +282,28 @@ def test_dropout_is_deterministic_and_unbiased(dev, K):
     assert abs(a.float().mean().item() - 1.0) < 5e-3
 
 
+def test_dropout_mask_independence(dev, K):
+    """the (seed, index) hash behind every fused dropout: drop events of neighbouring elements, of the same element in
+    neighbouring rows and of the same element under consecutive seeds are uncorrelated, for several seeds and rates"""
+    R, Ccols = 2048, 4096
+    x = torch.ones(R, Ccols, device=dev).bfloat16()
+    n = R * Ccols
+    for p in (0.05, 0.1, 0.5):
+        tol = 5.0 * (p * (1 - p) / n) ** 0.5 + 1e-4         # 5 sigma of the drop frequency
+        prev = None
+        for seed in (0, 1, 2, 12345, (1 << 40) + 7):
+            d = (K.dropout(x, p, seed) == 0).float()
+            assert abs(d.mean().item() - p) < tol, (p, seed, d.mean().item())
+            assert abs(d.mean(0) - p).max().item() < 6.0 * (p * (1 - p) / R) ** 0.5        # no dead / always-dropped column
+            z = d - p
+            var = p * (1 - p)
+            for a, b in ((z[:, 1:], z[:, :-1]), (z[:, 4:], z[:, :-4]), (z[1:], z[:-1]), (z[:, ::2], z[:, 1::2])):
+                assert abs((a * b).mean().item() / var) < 5e-3
+            if prev is not None:
+                assert abs((z * prev).mean().item() / var) < 5e-3
+            prev = z
+
+
 def test_gather_scatter_cast(dev, K):
     src = torch.randn(40, 64, device=dev).bfloat16()
     idx = torch.tensor([3, -1, 39, 0, 3], dtype=torch.int32, device=dev)
