@@ -385,13 +385,77 @@ def f11_vlm_inputs(R):
     torch.save(dict(cases=F11_CASES, outputs=outs, collated=padded), OUT / 'f11_vlm_inputs.pt')
 
 
+def f12_generation(R):
+    """generation path: prefill with use_cache, then teacher-forced single-token decode steps through the
+    reference's own `prepare_inputs_for_generation` (mmmm.py:368-406, the <p>/</p> position rule) and its KV-cache
+    attention (modeling_cogvlm.py:129-141, 253-262). The two kwargs
+    updates that live in transformers' GenerationMixin (absent from the transformers version of this image) are restated
+    here: attention_mask gets a column of ones, past_key_values is taken from the output; the reference's own parts
+    (token_type_ids += LANGUAGE, modeling_cogvlm.py:764-780; position_ids += last+1, mmmm.py:354-366) follow its code."""
+    g = torch.Generator().manual_seed(12)
+    m, cfg = build_tiny_model(R, False, seed=120)
+    m.eval()
+    images = [torch.randn(3, 1, 16, 32, generator=g), torch.randn(3, 8, 16, 32, generator=g), torch.randn(3, 4, 32, 16, generator=g)]
+    patch = [(1, 8, 8), (4, 8, 8), (2, 8, 8)]
+    pool = [(1, 2, 2), (2, 2, 2), (1, 1, 1)]
+    right = make_vlm_inputs([(2, 20), (2, 17), (16, 16)], L=44, g=g)
+    keys = ('input_ids', 'token_type_ids', 'position_ids', 'attention_mask')
+    BOP, EOP = m.tokenizer.bop_token_id, m.tokenizer.eop_token_id
+    forced = torch.tensor([[17, BOP, 33, 34, EOP, 9, 71],
+                           [BOP, 5, EOP, 88, 89, BOP, 90],
+                           [40, 41, 42, BOP, 43, EOP, 44]])
+    n_steps = forced.shape[1]
+    # The reference scatters image features at columns [1, 1+n) of every row (modeling_cogvlm.py:455-466), i.e. it assumes
+    # the prompt starts at column 0: a left-padded batch (what HF generate wants) cannot carry images. Each sample is
+    # therefore prefetched and decoded alone (batch of 1, no padding) -- what `_inference_path` (mmmm.py:408-424) does.
+    per_sample = []
+    with torch.no_grad():
+        for b in range(3):
+            n = int(right['attention_mask'][b].sum())
+            kw = {k: right[k][b:b + 1, :n].clone() for k in keys}
+            out = m(**kw, image=images[b:b + 1], patch_size=patch[b:b + 1], pool_size=pool[b:b + 1], use_cache=True, return_dict=True)
+            rec = dict(prefill=dict(**{k: v.clone() for k, v in kw.items()}), prefill_logits=out.logits.clone(), steps=[])
+            input_ids, token_type_ids, position_ids, attention_mask = (kw[k] for k in keys)
+            past = out.past_key_values
+            for t in range(n_steps):
+                # --- what generate() does between steps
+                input_ids = torch.cat([input_ids, forced[b:b + 1, t:t + 1]], dim=1)
+                attention_mask = torch.cat([attention_mask, torch.ones(1, 1, dtype=torch.long)], dim=1)              # GenerationMixin
+                token_type_ids = torch.cat([token_type_ids, torch.zeros(1, 1, dtype=torch.long)], dim=1)              # :764-780
+                position_ids = torch.cat([position_ids, position_ids[:, -1:] + 1], dim=1)                             # mmmm.py:354-366
+                inputs = m.prepare_inputs_for_generation(input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
+                                                         image=None, past_key_values=past, attention_mask=attention_mask,
+                                                         patch_size=None, pool_size=None, use_cache=True)
+                out = m(**inputs, return_dict=True)
+                past = out.past_key_values
+                rec['steps'].append(dict(token=int(forced[b, t]), position_id=int(inputs['position_ids'][0, -1]),
+                                         logits=out.logits[:, -1].clone()))
+            rec['final_position_ids'] = position_ids.clone()
+            per_sample.append(rec)
+    # the decode branch of attention_fn on its own, batched with padding inside the cache (modeling_cogvlm.py:129-141)
+    Bq, H, Lk, hd = 3, 2, 11, 32
+    q = torch.randn(Bq, H, 1, hd, generator=g)
+    k = torch.randn(Bq, H, Lk, hd, generator=g)
+    v = torch.randn(Bq, H, Lk, hd, generator=g)
+    pm = torch.ones(Bq, Lk, dtype=torch.bool)
+    pm[0, :4] = False
+    pm[2, 2:5] = False
+    attn_out = R.modeling_cogvlm.attention_fn(q.clone(), k.clone(), v.clone(), pm)
+    torch.save(dict(
+        state_dict={kk: vv.detach().clone() for kk, vv in m.state_dict().items()},
+        images=images, patch_size=patch, pool_size=pool, forced=forced, samples=per_sample,
+        bop_token_id=BOP, eop_token_id=EOP,
+        attn=dict(q=q, k=k, v=v, padding_mask=pm, out=attn_out),
+    ), OUT / 'f12_generation.pt')
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shims.load()
     only = os.environ.get('GOLDEN_ONLY')
-    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters, f11_vlm_inputs):
+    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters, f11_vlm_inputs, f12_generation):
         if only and only not in fn.__name__:
             continue
         fn(R)

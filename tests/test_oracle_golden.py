@@ -156,3 +156,35 @@ def test_f8_training_step_end_to_end():
     loss.backward()
     for name, g in f['grads'].items():
         close(sd[name].grad, g, 5e-5)
+
+
+def test_f12_generation_path_matches_the_reference():
+    """KV-cache decode, the <p>/</p> position rule and the single-query attention branch, against the
+    reference's own prefill + teacher-forced decode steps (oracle/make_golden.py::f12_generation)."""
+    f = load('f12_generation.pt')
+    a = f['attn']
+    close(O.decode_attention(a['q'], a['k'], a['v'], a['padding_mask']), a['out'], 1e-6)
+    sd, cfg = f['state_dict'], _tiny.lm_cfg()
+    for b, rec in enumerate(f['samples']):
+        pre = rec['prefill']
+        logits, _ = O.causal_lm_cached(sd, cfg, pre['input_ids'], token_type_ids=pre['token_type_ids'],
+                                       attention_mask=pre['attention_mask'], position_ids=pre['position_ids'],
+                                       image=f['images'][b:b + 1], patch_size=f['patch_size'][b:b + 1], pool_size=f['pool_size'][b:b + 1])
+        close(logits, rec['prefill_logits'])
+        forced = f['forced'][b:b + 1]
+        seq, step_logits, pos = O.generate(sd, cfg, pre['input_ids'], token_type_ids=pre['token_type_ids'],
+                                           position_ids=pre['position_ids'], image=f['images'][b:b + 1],
+                                           patch_size=f['patch_size'][b:b + 1], pool_size=f['pool_size'][b:b + 1],
+                                           bop_token_id=f['bop_token_id'], eop_token_id=f['eop_token_id'],
+                                           max_new_tokens=forced.shape[1], forced=forced)
+        assert torch.equal(seq[:, pre['input_ids'].shape[1]:], forced)
+        assert torch.equal(pos, rec['final_position_ids'])                        # integer rule: bit-exact
+        n0 = pre['input_ids'].shape[1]
+        for t, st in enumerate(rec['steps']):
+            assert int(pos[0, n0 + t]) == st['position_id']
+            close(step_logits[t], st['logits'])
+        # size-independent property: a cached decode step equals the last row of an uncached forward over the whole sequence
+        full = O.causal_lm_forward(sd, cfg, seq, image=f['images'][b:b + 1], patch_size=f['patch_size'][b:b + 1],
+                                   pool_size=f['pool_size'][b:b + 1], token_type_ids=torch.cat([pre['token_type_ids'], torch.zeros_like(forced)], 1),
+                                   attention_mask=torch.ones_like(seq), position_ids=pos)
+        close(full.logits[:, -1], step_logits[-1], 2e-5)
