@@ -320,6 +320,19 @@ typedef struct vm_attn_args {
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
 
+/* Single-query attention against a KV cache: the generation branch of attention_fn
+ * (modeling_cogvlm.py:129-141) with the cache handling of VisionExpertAttention.forward (:253-262).
+ * The cache of one layer is two bf16 arrays of token-major rows, k_cache / v_cache[b * ld_seq + t * ld_row + h * head_dim + d]
+ * for t < kv_lens_dev[b] (valid tokens only: no padding rows, no mask); q[b * ldq + h * head_dim + d] is the rotated
+ * query of the one new token of sample b, whose own K / V row has already been appended (kv_lens counts it).
+ * out[b * ldo + h * head_dim + d] = softmax_t(bf16(bf16(q * scale) . k_t)) . v_t, fp32 softmax. head_dim 32 / 64 / 128.
+ * max_len: host-side upper bound of kv_lens (sizes the launch; no device->host sync). Two launches: per-chunk partials
+ * (one wave per sample x head x 128 keys) and their merge; workspace from vm_attn_decode_workspace. Deterministic. */
+int vm_attn_decode_workspace(int batch, int n_heads, int head_dim, int max_len, int64_t* bytes_host);
+int vm_attn_decode_bf16(const void* q, int64_t ldq, const void* k_cache, const void* v_cache, int64_t ld_row, int64_t ld_seq,
+                        const int32_t* kv_lens_dev, void* out, int64_t ldo, int batch, int n_heads, int head_dim, int max_len,
+                        float scale, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* fp32 attention (SAM ViT-B encoder image_encoder.py:126-136 hd 64; two-way
  * transformer transformer.py:224-239 hd 96/48, tiny Lq or tiny Lk).
  * Dense batched form: q [Bn, Lq, H, hd], k/v [Bn, Lk, H, hd] given by strides. */

@@ -465,6 +465,32 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *
              dtype_code(p.dtype), stream())
 
 
+# ------------------------------------------------------------------ generation path
+@functools.lru_cache(maxsize=64)
+def _attn_decode_ws_bytes(batch: int, n_heads: int, head_dim: int, max_len: int) -> int:
+    n = C.c_int64(0)
+    hip.call('vm_attn_decode_workspace', batch, n_heads, head_dim, max_len, C.addressof(n))
+    return n.value
+
+
+def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_lens: torch.Tensor, n_heads: int, head_dim: int,
+                scale: float, max_len: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """single-query attention of one new token per sample against a KV cache (modeling_cogvlm.py:129-141).
+    q [B, H*hd] (row stride free), k_cache / v_cache [B, Lmax, H*hd] bf16, kv_lens int32[B] (new token included),
+    max_len: host upper bound of kv_lens -> [B, H*hd]"""
+    B = q.shape[0]
+    assert q.dtype == torch.bfloat16 and k_cache.dtype == torch.bfloat16 and v_cache.dtype == torch.bfloat16
+    assert q.stride(1) == 1 and k_cache.dim() == 3 and k_cache.stride(2) == 1 and k_cache.stride() == v_cache.stride()
+    assert kv_lens.dtype == torch.int32 and kv_lens.numel() == B and 0 < max_len <= k_cache.shape[1]
+    if out is None:
+        out = torch.empty(B, n_heads * head_dim, dtype=q.dtype, device=q.device)
+    nbytes = _attn_decode_ws_bytes(B, n_heads, head_dim, max_len)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+    hip.call('vm_attn_decode_bf16', ptr(q), _ld(q), ptr(k_cache), ptr(v_cache), k_cache.stride(1), k_cache.stride(0), ptr(kv_lens),
+             ptr(out), _ld(out), B, n_heads, head_dim, max_len, scale, ptr(ws), nbytes, stream())
+    return out
+
+
 # ------------------------------------------------------------------ profiling helpers
 def prof_enable(kinds=True):
     """kinds: True (every kind), False / () (off) or an iterable of hip.PROF_* kinds"""

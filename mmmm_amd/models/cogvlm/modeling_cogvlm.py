@@ -23,6 +23,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ... import functional as Fh
 from ... import kernels as K
+from .kv_cache import KVCache
 from ..lora import ActivationBudget, Linear, gated_linear
 from .configuration_cogvlm import CogVLMConfig
 from .visual import EVA2CLIPModel
@@ -105,12 +106,15 @@ class Routing:
     B: int
     L: int
     n_pos: int                  # rope table length (upper bound, host)
+    kv: object = None           # KVCache being filled by this forward (generation path), else None
+    kv_lens: torch.Tensor | None = None     # decode step: cached tokens per sample including the new one
 
 
 class VisionExpertAttention(nn.Module):
-    def __init__(self, config: CogVLMConfig):
+    def __init__(self, config: CogVLMConfig, layer_idx: int = 0):
         super().__init__()
         self.config = config
+        self.layer_idx = layer_idx
         self.hidden_size = config.hidden_size
         self.num_heads = config.num_attention_heads
         self.head_dim = self.hidden_size // self.num_heads
@@ -130,15 +134,21 @@ class VisionExpertAttention(nn.Module):
         qkv = gated_linear(x, self.vision_expert_query_key_value, self.language_expert_query_key_value, rt.counts)
         cos, sin = self.rotary_emb.tables(rt.n_pos, x.device)
         qkv = Fh.rope_(qkv, rt.row_pos, cos, sin, self.num_heads, self.head_dim, rt.n_rows)
-        ctx = Fh.attention(qkv, rt.cu_seqlens, rt.L, self.num_heads, self.head_dim, self.head_dim ** -0.5, True,
-                           row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L)
+        if rt.kv is not None:               # generation: the rotated K / V rows of this call join the cache (:253-262)
+            rt.kv.append(self.layer_idx, qkv, self.hidden_size, rt.n_rows)
+        if rt.kv_lens is not None:          # decode step: one query per sample against the cache (:129-141)
+            ctx = K.attn_decode(qkv[:, :self.hidden_size], rt.kv.k[self.layer_idx], rt.kv.v[self.layer_idx], rt.kv_lens,
+                                self.num_heads, self.head_dim, self.head_dim ** -0.5, rt.kv.len_bound + 1)
+        else:
+            ctx = Fh.attention(qkv, rt.cu_seqlens, rt.L, self.num_heads, self.head_dim, self.head_dim ** -0.5, True,
+                               row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L)
         return gated_linear(ctx, self.vision_expert_dense, self.language_expert_dense, rt.counts, residual=residual)
 
 
 class CogVLMDecoderLayer(nn.Module):
-    def __init__(self, config: CogVLMConfig):
+    def __init__(self, config: CogVLMConfig, layer_idx: int = 0):
         super().__init__()
-        self.self_attn = VisionExpertAttention(config)
+        self.self_attn = VisionExpertAttention(config, layer_idx)
         self.mlp = VisionExpertMLP(config)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
@@ -174,7 +184,7 @@ class CogVLMModel(nn.Module):
         self.padding_idx = config.pad_token_id
         self.vocab_size = config.vocab_size
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
-        self.layers = nn.ModuleList([CogVLMDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.layers = nn.ModuleList([CogVLMDecoderLayer(config, i) for i in range(config.num_hidden_layers)])
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.vision = EVA2CLIPModel(config)
         self.gradient_checkpointing = False
@@ -202,7 +212,8 @@ class CogVLMModel(nn.Module):
                        B=B, L=L, n_pos=n_pos)
 
     def forward(self, input_ids, *, image=None, patch_size=None, pool_size=None, token_type_ids=None, attention_mask=None,
-                position_ids=None, output_hidden_states: bool = False):
+                position_ids=None, output_hidden_states: bool = False, kv_cache: KVCache | None = None):
+        """kv_cache: an EMPTY cache to fill (prefill of the generation path, `use_cache=True` with no past)"""
         B, L = input_ids.shape
         dev = input_ids.device
         if token_type_ids is None:
@@ -212,6 +223,15 @@ class CogVLMModel(nn.Module):
         if position_ids is None:
             position_ids = torch.arange(L, device=dev)[None].expand(B, L)
         rt = self.build_routing(token_type_ids, attention_mask, position_ids)
+        if kv_cache is not None:
+            assert not torch.is_grad_enabled() or not self.training, 'the KV cache is an inference-only structure'
+            # packed rows are expert-sorted, not sequence-ordered: a row's cache slot is (its sample, its rank among the
+            # sample's valid tokens)
+            tok = rt.tok_of_row.clamp_min(0).long()
+            rank = (attention_mask.to(torch.int32).cumsum(1, dtype=torch.int32) - 1).reshape(-1)
+            kv_cache.begin(torch.div(tok, L, rounding_mode='floor').to(torch.int32), rank[tok],
+                           rt.cu_seqlens[1:] - rt.cu_seqlens[:-1], L)
+            rt.kv = kv_cache
         # token ids per packed row; rows that will be overwritten by image features look up nothing (-1)
         ids = input_ids.reshape(-1).to(torch.int32)
         feats = None
@@ -243,7 +263,31 @@ class CogVLMModel(nn.Module):
         x = self.norm(x, rt.n_rows)
         if hs is not None:
             hs.append(x)
+        if kv_cache is not None:
+            kv_cache.commit()
         return x, rt, (PackedHidden(hs, rt) if hs is not None else None)
+
+    @torch.no_grad()
+    def decode_step(self, input_ids: torch.Tensor, position_ids: torch.Tensor, kv_cache: KVCache) -> torch.Tensor:
+        """one new token per sample against the cache: input_ids, position_ids [B] (device). A single-token call never
+        touches the vision expert (get_expert_mask with L == 1, reference :58-70) and skips the padding-masked norms
+        (:306-309), so every row is a language row. No host synchronisation. -> final hidden [B, h]"""
+        B = input_ids.shape[0]
+        dev = input_ids.device
+        assert B == kv_cache.batch
+        ar = torch.arange(B, device=dev, dtype=torch.int32)
+        ones = torch.ones(B, device=dev, dtype=torch.int32)
+        kv_cache.begin(ar, torch.zeros_like(ar), ones, 1)
+        counts = torch.tensor([0, B, 1, 0], dtype=torch.int32).to(dev, non_blocking=True)     # no vision rows
+        rt = Routing(counts=counts, row_of_tok=ar, tok_of_row=ar, cu_seqlens=torch.arange(B + 1, device=dev, dtype=torch.int32),
+                     row_of_pos=ar, expert_mask=None, row_pos=position_ids.to(torch.int32).contiguous(), n_rows=counts[1:2],
+                     B=B, L=1, n_pos=int(self.config.max_position_embeddings), kv=kv_cache, kv_lens=kv_cache.lens_after())
+        x = Fh.embedding_rows(self.embed_tokens.weight, input_ids.to(torch.int32).contiguous())
+        for layer in self.layers:
+            x = layer(x, rt)
+        x = self.norm(x, rt.n_rows)
+        kv_cache.commit()
+        return x
 
 
 class _LMHeadCE(torch.autograd.Function):
@@ -304,6 +348,12 @@ class CogVLMForCausalLM(nn.Module):
         self.vocab_size = config.vocab_size
         self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False)
 
+    default_max_new_tokens = 256
+
+    def new_kv_cache(self, batch: int, max_len: int, device) -> KVCache:
+        cfg = self.config
+        return KVCache(cfg.num_hidden_layers, batch, max_len, cfg.hidden_size, device, dtype=self.lm_head.weight.dtype)
+
     def gradient_checkpointing_enable(self, kwargs: dict | None = None):
         self.model.gradient_checkpointing = True
         self.model.vision.transformer.gradient_checkpointing = True
@@ -311,13 +361,23 @@ class CogVLMForCausalLM(nn.Module):
     def forward(self, input_ids=None, *, image=None, patch_size=None, pool_size=None, token_type_ids=None,
                 attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, weight=None,
-                materialize_logits: bool = False) -> CausalLMOutputWithPast:
-        if past_key_values is not None or inputs_embeds is not None:
-            raise NotImplementedError('generation path (SURVEY.md §8f N4) is out of scope of the training step')
+                materialize_logits: bool | None = None) -> CausalLMOutputWithPast:
+        if inputs_embeds is not None:
+            raise NotImplementedError('inputs_embeds is not part of the reference\'s own call sites of this path')
+        if past_key_values is not None and len(past_key_values) > 0:
+            # decode step of the generation path (reference :441-442, 253-262): the last column is the new token
+            assert labels is None and input_ids.shape[1] >= 1
+            x = self.model.decode_step(input_ids[:, -1], position_ids[:, -1], past_key_values)
+            logits = K.gemm(x, self.lm_head.weight.detach()).float()
+            return CausalLMOutputWithPast(logits=logits[:, None], past_key_values=past_key_values, last_hidden_packed=x)
+        cache = None
+        if use_cache:
+            cache = past_key_values if past_key_values is not None else self.new_kv_cache(
+                input_ids.shape[0], input_ids.shape[1] + self.default_max_new_tokens, input_ids.device)
         x, rt, hs = self.model(input_ids, image=image, patch_size=patch_size, pool_size=pool_size, token_type_ids=token_type_ids,
                                attention_mask=attention_mask, position_ids=position_ids,
-                               output_hidden_states=bool(output_hidden_states))
-        out = CausalLMOutputWithPast(hidden_states=hs, routing=rt, last_hidden_packed=x)
+                               output_hidden_states=bool(output_hidden_states), kv_cache=cache)
+        out = CausalLMOutputWithPast(hidden_states=hs, routing=rt, last_hidden_packed=x, past_key_values=cache)
         if labels is not None:
             tok = rt.tok_of_row.clamp_min(0).long()
             row_labels = torch.where(rt.tok_of_row >= 0, labels.reshape(-1)[tok], torch.full_like(tok, CE_IGNORE_INDEX)).contiguous()
@@ -330,7 +390,7 @@ class CogVLMForCausalLM(nn.Module):
                 pass  # F.cross_entropy mean over valid labels == weighted form with unit weights
             out.loss, out.row_ce = loss, row_ce
             out.row_labels = row_labels
-        if materialize_logits or labels is None:
+        if materialize_logits or (materialize_logits is None and labels is None):
             lg = K.gemm(x.detach(), self.lm_head.weight.detach())
             full = K.gather_rows(lg, rt.row_of_tok, rt.B * rt.L)
             out.logits = full.view(rt.B, rt.L, -1).float()

@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fh
+from .. import kernels as K
 from ..utils import apply_prefix, get_lora_modules_default, get_lora_modules_finetune_all
 from .cogvlm.configuration_cogvlm import CogVLMConfig
 from .cogvlm.modeling_cogvlm import CausalLMOutputWithPast, CogVLMForCausalLM
@@ -314,6 +315,104 @@ class MMMMForCausalLM(CogVLMForCausalLM):
                 logs[f'train/token-lm/{name}_count'] = n
         self.log_dict(logs)
         return loss
+
+
+    # -- generation path --------------------------------------------------------
+    def prepare_inputs_for_generation(self, input_ids, *, token_type_ids, position_ids, image=None, past_key_values=None,
+                                      attention_mask=None, inputs_embeds=None, patch_size, pool_size, **kwargs):
+        """mmmm.py:368-406. With a non-empty cache only the last column is fed, and its position is corrected IN PLACE
+        (as the reference does): the token right after <p> and a </p> itself keep the position of their predecessor."""
+        if past_key_values:
+            keep_position = (input_ids[:, -2] == self.tokenizer.bop_token_id) | (input_ids[:, -1] == self.tokenizer.eop_token_id)
+            position_ids[:, -1] -= keep_position.long()
+            input_ids = input_ids[:, -1:]
+            token_type_ids = token_type_ids[:, -1:]
+            position_ids = position_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs = {'inputs_embeds': inputs_embeds}
+        else:
+            model_inputs = {'input_ids': input_ids}
+        model_inputs.update({
+            'image': image, 'token_type_ids': token_type_ids, 'position_ids': position_ids, 'past_key_values': past_key_values,
+            'attention_mask': attention_mask, 'patch_size': patch_size, 'pool_size': pool_size, 'use_cache': kwargs.get('use_cache'),
+        })
+        return model_inputs
+
+    @torch.no_grad()
+    def generate(self, input_ids, *, token_type_ids, position_ids, image, patch_size, pool_size, attention_mask=None,
+                 max_new_tokens: int = 32, eos_token_id: int | None = None, forced_tokens: torch.Tensor | None = None,
+                 eos_check_every: int = 16, return_logits: bool = False) -> GenerateOutput:
+        """Greedy decoding (`num_beams=1`, what scripts/demo.py and `evaluate`, mmmm.py:426-452, use): one prefill that fills
+        the KV cache, then one token per sample and step. Unlike the reference (whose image scatter assumes column 1 and
+        whose HF loop wants left padding, so images force batch size 1) a RIGHT-padded prompt batch is decoded together:
+        the cache holds valid tokens only. The <p>/</p> position rule (mmmm.py:354-366, 383-386) runs on the device; the
+        loop synchronises with the host only every `eos_check_every` steps to test for early termination.
+        `forced_tokens` [B, steps] replaces the arg-max choice (teacher forcing for parity tests)."""
+        was_training = self.training
+        self.eval()
+        try:
+            B, L = input_ids.shape
+            dev = input_ids.device
+            if attention_mask is None:
+                attention_mask = torch.ones_like(input_ids)
+            steps = max_new_tokens if forced_tokens is None else forced_tokens.shape[1]
+            cache = self.new_kv_cache(B, L + steps, dev)
+            out = self(input_ids, image=image, patch_size=patch_size, pool_size=pool_size, token_type_ids=token_type_ids,
+                       attention_mask=attention_mask, position_ids=position_ids, past_key_values=cache, use_cache=True,
+                       materialize_logits=False)
+            # last valid token of every sample: its hidden state predicts the first new token
+            am = attention_mask.bool()
+            n_valid = am.sum(1)
+            last_col = (torch.arange(L, device=dev)[None] * am).argmax(1)
+            rt = out.routing
+            last_row = rt.row_of_tok.long()[torch.arange(B, device=dev) * L + last_col]
+            logits = K.gemm(out.last_hidden_packed[last_row].contiguous(), self.lm_head.weight.detach()).float()
+            prev_tok = input_ids[torch.arange(B, device=dev), last_col]
+            pos = position_ids[torch.arange(B, device=dev), last_col]
+            bop, eop = self.tokenizer.bop_token_id, self.tokenizer.eop_token_id
+            done = torch.zeros(B, dtype=torch.bool, device=dev)
+            new_tokens, new_pos, all_logits = [], [], ([logits] if return_logits else None)
+            for t in range(steps):
+                tok = forced_tokens[:, t] if forced_tokens is not None else logits.argmax(-1)
+                if eos_token_id is not None:
+                    tok = torch.where(done, torch.full_like(tok, eos_token_id), tok)
+                    done = done | (tok == eos_token_id)
+                pos = pos + 1 - ((prev_tok == bop) | (tok == eop)).long()
+                new_tokens.append(tok)
+                new_pos.append(pos)
+                if t + 1 == steps:
+                    break
+                if forced_tokens is None and eos_token_id is not None and (t + 1) % eos_check_every == 0 and bool(done.all()):
+                    break
+                x = self.model.decode_step(tok, pos, cache)
+                logits = K.gemm(x, self.lm_head.weight.detach()).float()
+                if return_logits:
+                    all_logits.append(logits)
+                prev_tok = tok
+            return GenerateOutput(new_tokens=torch.stack(new_tokens, 1), new_position_ids=torch.stack(new_pos, 1), prompt_lengths=n_valid,
+                                  logits=all_logits, past_key_values=cache)
+        finally:
+            self.train(was_training)
+
+
+@dataclass
+class GenerateOutput:
+    new_tokens: torch.Tensor            # [B, steps] generated (or forced) tokens; eos-filled after a sample has finished
+    new_position_ids: torch.Tensor      # [B, steps] their position ids under the <p>/</p> rule
+    prompt_lengths: torch.Tensor        # [B] valid prompt tokens per sample
+    logits: list | None = None          # per step [B, V] fp32: logits[t] chose new_tokens[:, t]
+    past_key_values: object = None
+
+    def sequences(self, input_ids: torch.Tensor, pad_token_id: int = 0) -> torch.Tensor:
+        """prompt and continuation in one right-padded [B, L + steps] tensor (HF `generate` layout when nothing is padded)"""
+        B, L = input_ids.shape
+        steps = self.new_tokens.shape[1]
+        seq = torch.full((B, L + steps), pad_token_id, dtype=input_ids.dtype, device=input_ids.device)
+        ar = torch.arange(L + steps, device=input_ids.device)[None]
+        n = self.prompt_lengths[:, None]
+        seq[:, :L] = torch.where(ar[:, :L] < n, input_ids, seq[:, :L])
+        idx = (n + torch.arange(steps, device=input_ids.device)[None])
+        return seq.scatter(1, idx, self.new_tokens.to(seq.dtype))
 
 
 def build(*args, **kwargs) -> MMMMForCausalLM:
