@@ -320,6 +320,15 @@ typedef struct vm_attn_args {
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
 
+/* Skinny-M linear of the decode step (one row per sample): out[M,N] = x[M,K] W[N,K]^T + alpha2 * x2[M,K2] W2[N,K2]^T
+ * + bias[N], then (rounded to bf16) + residual[M,N] — the language-expert nn.Linear calls of
+ * modeling_cogvlm.py:243-245, 277-279, 54-56 and lm_head (:706) when L == 1. bf16 operands, fp32 accumulation.
+ * M <= 16, K % 64 == 0, K2 % 64 == 0 (else VM_ERR_UNSUPPORTED: use vm_gemm_bf16). x2 / W2 / bias / residual may be
+ * NULL. HBM-bound: W is read once, N/16 workgroups of 16 waves, no workspace, deterministic. */
+int vm_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* x2, int64_t ldx2, const void* W2, int64_t ldw2,
+                 float alpha2, const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                 int K2, void* stream);
+
 /* Single-query attention against a KV cache: the generation branch of attention_fn
  * (modeling_cogvlm.py:129-141) with the cache handling of VisionExpertAttention.forward (:253-262).
  * The cache of one layer is two bf16 arrays of token-major rows, k_cache / v_cache[b * ld_seq + t * ld_row + h * head_dim + d]

@@ -491,6 +491,26 @@ def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, k
     return out
 
 
+def gemv_supported(x: torch.Tensor, w: torch.Tensor, a2: torch.Tensor | None = None) -> bool:
+    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] <= 16 and x.shape[1] % 64 == 0
+            and (a2 is None or a2.shape[1] % 64 == 0))
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, *, a2: torch.Tensor | None = None, b2: torch.Tensor | None = None, alpha2: float = 1.0,
+         bias: torch.Tensor | None = None, residual: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[M<=16, N] = x w^T + alpha2 * a2 b2^T + bias (+ residual after rounding), bf16, W streamed once (decode step)"""
+    M, Kd = x.shape
+    N = w.shape[0]
+    assert gemv_supported(x, w, a2) and w.shape[1] == Kd and (a2 is None) == (b2 is None)
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    K2 = 0 if a2 is None else a2.shape[1]
+    hip.call('vm_gemv_bf16', ptr(x), _ld(x), ptr(w), _ld(w), ptr(a2), _ld(a2) if a2 is not None else 0, ptr(b2),
+             _ld(b2) if b2 is not None else 0, alpha2, ptr(bias), ptr(residual), _ld(residual) if residual is not None else 0,
+             ptr(out), _ld(out), M, N, Kd, K2, stream())
+    return out
+
+
 # ------------------------------------------------------------------ profiling helpers
 def prof_enable(kinds=True):
     """kinds: True (every kind), False / () (off) or an iterable of hip.PROF_* kinds"""

@@ -21,8 +21,17 @@ class KVCache:
         self.lens = torch.zeros(batch, dtype=torch.int32, device=device)       # tokens cached per sample (device)
         self.max_len = max_len
         self.len_bound = 0            # host upper bound of lens (max over samples)
+        # launch bound of the decode attention: None = len_bound + 1 (eager); a captured decode step (hipGraph) is replayed
+        # with one fixed geometry, so it is sized for the whole cache and the chunks past a sample's length exit at once
+        self.launch_bound: int | None = None
         self._slots: torch.Tensor | None = None
         self._pending: torch.Tensor | None = None
+        # constants of a decode step (one row per sample), created once: nothing is uploaded inside a step
+        self.rows = torch.arange(batch, device=device, dtype=torch.int32)
+        self.zeros = torch.zeros(batch, device=device, dtype=torch.int32)
+        self.ones = torch.ones(batch, device=device, dtype=torch.int32)
+        self.cu_rows = torch.arange(batch + 1, device=device, dtype=torch.int32)
+        self.decode_counts = torch.tensor([0, batch, 1, 0], dtype=torch.int32, device=device)     # no vision rows
 
     @property
     def batch(self) -> int:
@@ -51,8 +60,11 @@ class KVCache:
     def lens_after(self) -> torch.Tensor:
         return self.lens + self._pending
 
+    def attn_bound(self) -> int:
+        return self.launch_bound if self.launch_bound is not None else self.len_bound + 1
+
     def commit(self):
         """all layers have appended: advance the lengths"""
-        self.lens = self.lens + self._pending
+        self.lens.add_(self._pending)
         self.len_bound += self._pending_bound
         self._slots = self._pending = None

@@ -24,7 +24,7 @@ from torch.utils.checkpoint import checkpoint
 from ... import functional as Fh
 from ... import kernels as K
 from .kv_cache import KVCache
-from ..lora import ActivationBudget, Linear, gated_linear
+from ..lora import ActivationBudget, Linear, gated_linear, linear_decode
 from .configuration_cogvlm import CogVLMConfig
 from .visual import EVA2CLIPModel
 
@@ -63,8 +63,11 @@ class VisionExpertMLP(nn.Module):
             return get_lora_modules_default(self, prefix, False)
         return get_lora_modules_default(self.vision_mlp, apply_prefix(prefix, 'vision_mlp'))
 
-    def forward(self, x: torch.Tensor, counts: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, counts: torch.Tensor, residual: torch.Tensor, decode: bool = False) -> torch.Tensor:
         v, l = self.vision_mlp, self.language_mlp
+        if decode:      # a single-token call only ever reaches the language expert (reference :58-70 with L == 1)
+            h = Fh.silu_mul(linear_decode(x, l.gate_proj), linear_decode(x, l.up_proj))
+            return linear_decode(h, l.down_proj, residual)
         gate = gated_linear(x, v.gate_proj, l.gate_proj, counts)
         up = gated_linear(x, v.up_proj, l.up_proj, counts)
         return gated_linear(Fh.silu_mul(gate, up), v.down_proj, l.down_proj, counts, residual=residual)
@@ -131,17 +134,23 @@ class VisionExpertAttention(nn.Module):
         return [apply_prefix(prefix, 'vision_expert_query_key_value'), apply_prefix(prefix, 'vision_expert_dense')], []
 
     def forward(self, x: torch.Tensor, rt: Routing, residual: torch.Tensor) -> torch.Tensor:
-        qkv = gated_linear(x, self.vision_expert_query_key_value, self.language_expert_query_key_value, rt.counts)
+        decode = rt.kv_lens is not None
+        if decode:
+            qkv = linear_decode(x, self.language_expert_query_key_value)
+        else:
+            qkv = gated_linear(x, self.vision_expert_query_key_value, self.language_expert_query_key_value, rt.counts)
         cos, sin = self.rotary_emb.tables(rt.n_pos, x.device)
         qkv = Fh.rope_(qkv, rt.row_pos, cos, sin, self.num_heads, self.head_dim, rt.n_rows)
         if rt.kv is not None:               # generation: the rotated K / V rows of this call join the cache (:253-262)
             rt.kv.append(self.layer_idx, qkv, self.hidden_size, rt.n_rows)
         if rt.kv_lens is not None:          # decode step: one query per sample against the cache (:129-141)
             ctx = K.attn_decode(qkv[:, :self.hidden_size], rt.kv.k[self.layer_idx], rt.kv.v[self.layer_idx], rt.kv_lens,
-                                self.num_heads, self.head_dim, self.head_dim ** -0.5, rt.kv.len_bound + 1)
+                                self.num_heads, self.head_dim, self.head_dim ** -0.5, rt.kv.attn_bound())
         else:
             ctx = Fh.attention(qkv, rt.cu_seqlens, rt.L, self.num_heads, self.head_dim, self.head_dim ** -0.5, True,
                                row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L)
+        if decode:
+            return linear_decode(ctx, self.language_expert_dense, residual)
         return gated_linear(ctx, self.vision_expert_dense, self.language_expert_dense, rt.counts, residual=residual)
 
 
@@ -155,7 +164,7 @@ class CogVLMDecoderLayer(nn.Module):
 
     def forward(self, x: torch.Tensor, rt: Routing) -> torch.Tensor:
         x = self.self_attn(self.input_layernorm(x, rt.n_rows), rt, residual=x)
-        return self.mlp(self.post_attention_layernorm(x, rt.n_rows), rt.counts, residual=x)
+        return self.mlp(self.post_attention_layernorm(x, rt.n_rows), rt.counts, residual=x, decode=rt.kv_lens is not None)
 
 
 class PackedHidden:
@@ -273,15 +282,12 @@ class CogVLMModel(nn.Module):
         touches the vision expert (get_expert_mask with L == 1, reference :58-70) and skips the padding-masked norms
         (:306-309), so every row is a language row. No host synchronisation. -> final hidden [B, h]"""
         B = input_ids.shape[0]
-        dev = input_ids.device
-        assert B == kv_cache.batch
-        ar = torch.arange(B, device=dev, dtype=torch.int32)
-        ones = torch.ones(B, device=dev, dtype=torch.int32)
-        kv_cache.begin(ar, torch.zeros_like(ar), ones, 1)
-        counts = torch.tensor([0, B, 1, 0], dtype=torch.int32).to(dev, non_blocking=True)     # no vision rows
-        rt = Routing(counts=counts, row_of_tok=ar, tok_of_row=ar, cu_seqlens=torch.arange(B + 1, device=dev, dtype=torch.int32),
-                     row_of_pos=ar, expert_mask=None, row_pos=position_ids.to(torch.int32).contiguous(), n_rows=counts[1:2],
-                     B=B, L=1, n_pos=int(self.config.max_position_embeddings), kv=kv_cache, kv_lens=kv_cache.lens_after())
+        c = kv_cache
+        assert B == c.batch
+        c.begin(c.rows, c.zeros, c.ones, 1)
+        rt = Routing(counts=c.decode_counts, row_of_tok=c.rows, tok_of_row=c.rows, cu_seqlens=c.cu_rows, row_of_pos=c.rows,
+                     expert_mask=None, row_pos=position_ids.to(torch.int32).contiguous(), n_rows=c.decode_counts[1:2],
+                     B=B, L=1, n_pos=int(self.config.max_position_embeddings), kv=c, kv_lens=c.lens_after())
         x = Fh.embedding_rows(self.embed_tokens.weight, input_ids.to(torch.int32).contiguous())
         for layer in self.layers:
             x = layer(x, rt)
@@ -368,7 +374,7 @@ class CogVLMForCausalLM(nn.Module):
             # decode step of the generation path (reference :441-442, 253-262): the last column is the new token
             assert labels is None and input_ids.shape[1] >= 1
             x = self.model.decode_step(input_ids[:, -1], position_ids[:, -1], past_key_values)
-            logits = K.gemm(x, self.lm_head.weight.detach()).float()
+            logits = linear_decode(x, self.lm_head).float()
             return CausalLMOutputWithPast(logits=logits[:, None], past_key_values=past_key_values, last_hidden_packed=x)
         cache = None
         if use_cache:

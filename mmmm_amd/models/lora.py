@@ -156,6 +156,19 @@ class Linear(nn.Module):
         return y.view(*shape[:-1], self.out_features)
 
 
+@torch.no_grad()
+def linear_decode(x: torch.Tensor, lin: Linear, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """one Linear (LoRA included, dropout off) on the few rows of a decode step: W is streamed once by the skinny-M kernel
+    (`vm_gemv_bf16`) when the shape allows, else by the tiled GEMM"""
+    t = None
+    if lin.lora_cfg is not None:
+        t = Fh._lora_project(x, lin.A, None, False, None)
+    scale = lin.lora_cfg.scale if lin.lora_cfg is not None else 1.0
+    if K.gemv_supported(x, lin.weight, t):
+        return K.gemv(x, lin.weight, a2=t, b2=lin.B, alpha2=scale, bias=lin.bias, residual=residual)
+    return K.gemm(x, lin.weight, a2=t, b2=lin.B, alpha2=scale, bias=lin.bias, residual=residual)
+
+
 def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torch.Tensor, residual: torch.Tensor | None = None):
     """token-type gated pair of linears on the expert-sorted row layout: rows [0,counts[0]) -> `vision`,
     rows [counts[0],counts[1]) -> `language` (reference modeling_cogvlm.py:243-245, 277-279, 95-97)."""

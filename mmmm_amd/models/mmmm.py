@@ -21,7 +21,7 @@ from .. import kernels as K
 from ..utils import apply_prefix, get_lora_modules_default, get_lora_modules_finetune_all
 from .cogvlm.configuration_cogvlm import CogVLMConfig
 from .cogvlm.modeling_cogvlm import CausalLMOutputWithPast, CogVLMForCausalLM
-from .lora import ActivationBudget, Linear, LoraTransposes, StepState
+from .lora import ActivationBudget, Linear, LoraTransposes, StepState, linear_decode
 from .loss import DiceFocalLoss
 
 __all__ = ['MMMMForCausalLM', 'build', 'VisionArgs', 'MyPrecision']
@@ -341,13 +341,15 @@ class MMMMForCausalLM(CogVLMForCausalLM):
     @torch.no_grad()
     def generate(self, input_ids, *, token_type_ids, position_ids, image, patch_size, pool_size, attention_mask=None,
                  max_new_tokens: int = 32, eos_token_id: int | None = None, forced_tokens: torch.Tensor | None = None,
-                 eos_check_every: int = 16, return_logits: bool = False) -> GenerateOutput:
+                 eos_check_every: int = 16, return_logits: bool = False, use_graph: bool = False) -> GenerateOutput:
         """Greedy decoding (`num_beams=1`, what scripts/demo.py and `evaluate`, mmmm.py:426-452, use): one prefill that fills
         the KV cache, then one token per sample and step. Unlike the reference (whose image scatter assumes column 1 and
         whose HF loop wants left padding, so images force batch size 1) a RIGHT-padded prompt batch is decoded together:
         the cache holds valid tokens only. The <p>/</p> position rule (mmmm.py:354-366, 383-386) runs on the device; the
         loop synchronises with the host only every `eos_check_every` steps to test for early termination.
-        `forced_tokens` [B, steps] replaces the arg-max choice (teacher forcing for parity tests)."""
+        `forced_tokens` [B, steps] replaces the arg-max choice (teacher forcing for parity tests). `use_graph` captures one
+        decode step (32 layers of ~25 launches + token choice) into a hipGraph and replays it: a step is launch-bound
+        otherwise (16.5 ms eager vs ~3 ms of HBM time at batch 1)."""
         was_training = self.training
         self.eval()
         try:
@@ -366,26 +368,35 @@ class MMMMForCausalLM(CogVLMForCausalLM):
             last_col = (torch.arange(L, device=dev)[None] * am).argmax(1)
             rt = out.routing
             last_row = rt.row_of_tok.long()[torch.arange(B, device=dev) * L + last_col]
-            logits = K.gemm(out.last_hidden_packed[last_row].contiguous(), self.lm_head.weight.detach()).float()
+            logits = linear_decode(out.last_hidden_packed[last_row].contiguous(), self.lm_head).float()
             prev_tok = input_ids[torch.arange(B, device=dev), last_col]
             pos = position_ids[torch.arange(B, device=dev), last_col]
             bop, eop = self.tokenizer.bop_token_id, self.tokenizer.eop_token_id
             done = torch.zeros(B, dtype=torch.bool, device=dev)
-            new_tokens, new_pos, all_logits = [], [], ([logits] if return_logits else None)
-            for t in range(steps):
+            head = self.lm_head.weight.detach()
+
+            def choose(logits, prev_tok, pos, done, t):
+                """next token (arg-max or forced), eos bookkeeping and the <p>/</p> position rule (mmmm.py:354-366,383-386)"""
                 tok = forced_tokens[:, t] if forced_tokens is not None else logits.argmax(-1)
                 if eos_token_id is not None:
                     tok = torch.where(done, torch.full_like(tok, eos_token_id), tok)
                     done = done | (tok == eos_token_id)
-                pos = pos + 1 - ((prev_tok == bop) | (tok == eop)).long()
+                return tok, pos + 1 - ((prev_tok == bop) | (tok == eop)).long(), done
+
+            if use_graph and forced_tokens is None and not return_logits and steps > 2:
+                new_tokens, new_pos = self._generate_graphed(cache, head, logits, prev_tok, pos, done, steps, eos_token_id, bop, eop,
+                                                             eos_check_every)
+                return GenerateOutput(new_tokens=new_tokens, new_position_ids=new_pos, prompt_lengths=n_valid, past_key_values=cache)
+            new_tokens, new_pos, all_logits = [], [], ([logits] if return_logits else None)
+            for t in range(steps):
+                tok, pos, done = choose(logits, prev_tok, pos, done, t)
                 new_tokens.append(tok)
                 new_pos.append(pos)
                 if t + 1 == steps:
                     break
                 if forced_tokens is None and eos_token_id is not None and (t + 1) % eos_check_every == 0 and bool(done.all()):
                     break
-                x = self.model.decode_step(tok, pos, cache)
-                logits = K.gemm(x, self.lm_head.weight.detach()).float()
+                logits = linear_decode(self.model.decode_step(tok, pos, cache), self.lm_head).float()
                 if return_logits:
                     all_logits.append(logits)
                 prev_tok = tok
@@ -393,6 +404,58 @@ class MMMMForCausalLM(CogVLMForCausalLM):
                                   logits=all_logits, past_key_values=cache)
         finally:
             self.train(was_training)
+
+
+    def _generate_graphed(self, cache, head, logits, prev_tok, pos, done, steps, eos_token_id, bop, eop, eos_check_every):
+        """greedy loop with the decode step captured in a hipGraph. State lives in static device buffers that the graph
+        updates in place: (tok, pos, done) of the newest token, a step counter, and the [B, steps] outputs it scatters into.
+        One eager step first: it sets the lazily-initialised kernel attributes and warms the allocator outside the capture."""
+        B = prev_tok.shape[0]
+        dev = prev_tok.device
+        out_tok = torch.full((B, steps), eos_token_id if eos_token_id is not None else 0, dtype=torch.long, device=dev)
+        out_pos = torch.zeros(B, steps, dtype=torch.long, device=dev)
+
+        def choose(logits, prev_tok, pos, done):
+            tok = logits.argmax(-1)
+            if eos_token_id is not None:
+                tok = torch.where(done, torch.full_like(tok, eos_token_id), tok)
+                done = done | (tok == eos_token_id)
+            return tok, pos + 1 - ((prev_tok == bop) | (tok == eop)).long(), done
+
+        tok, pos, done = choose(logits, prev_tok, pos, done)
+        out_tok[:, 0], out_pos[:, 0] = tok, pos
+        logits = linear_decode(self.model.decode_step(tok, pos, cache), self.lm_head).float()          # eager step 1
+        s_prev, s_pos, s_done = tok.clone(), pos.clone(), done.clone()
+        s_logits = logits.clone()
+        s_col = torch.ones(B, 1, dtype=torch.long, device=dev)
+        cache.launch_bound = cache.max_len
+
+        def step():
+            tok, pos, done = choose(s_logits, s_prev, s_pos, s_done)
+            out_tok.scatter_(1, s_col, tok[:, None])
+            out_pos.scatter_(1, s_col, pos[:, None])
+            s_col.add_(1)
+            s_logits.copy_(linear_decode(self.model.decode_step(tok, pos, cache), self.lm_head).float())
+            s_prev.copy_(tok); s_pos.copy_(pos); s_done.copy_(done)
+
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        bound0 = cache.len_bound
+        with torch.cuda.graph(graph):
+            step()
+        cache.len_bound = bound0                  # the capture ran the host bookkeeping once without executing anything
+        t = 1
+        while t < steps - 1:
+            graph.replay()
+            cache.len_bound += 1
+            t += 1
+            if eos_token_id is not None and t % eos_check_every == 0 and bool(s_done.all()):
+                break
+        if t == steps - 1:                        # the last token needs no decode step after it
+            tok, pos, _ = choose(s_logits, s_prev, s_pos, s_done)
+            out_tok[:, t], out_pos[:, t] = tok, pos
+        cache.launch_bound = None
+        return out_tok, out_pos
 
 
 @dataclass

@@ -55,6 +55,32 @@ def test_attn_decode_kernel(dev, K, hd):
     assert torch.equal(got2, got[:4])
 
 
+@pytest.mark.parametrize('M,N,Kd', [(1, 4096, 4096), (8, 1000, 704), (16, 264, 1152), (3, 16, 64)])
+def test_gemv_kernel(dev, K, M, N, Kd):
+    """skinny-M linear of the decode step vs fp32 torch: plain, with LoRA extension, bias and residual (torch's rounding:
+    the linear is rounded to bf16 before the residual add); N tails, odd block counts, M = 1 .. 16; bit-reproducible"""
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = torch.randn(M, Kd, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16().to(dev)
+    t = torch.randn(M, 64, generator=g).bfloat16().to(dev)
+    b2 = (torch.randn(N, 64, generator=g) / 8).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).bfloat16().to(dev)
+    res = torch.randn(M, N, generator=g).bfloat16().to(dev)
+    base = x.float() @ w.float().T
+    assert rel(K.gemv(x, w).float(), base) < 4e-3
+    full = base + 0.5 * (t.float() @ b2.float().T) + bias.float()
+    want = full.bfloat16().float() + res.float()
+    got = K.gemv(x, w, a2=t, b2=b2, alpha2=0.5, bias=bias, residual=res)
+    assert rel(got.float(), want) < 4e-3
+    assert torch.equal(got, K.gemv(x, w, a2=t, b2=b2, alpha2=0.5, bias=bias, residual=res))
+    # same contraction as the tiled GEMM (different summation order only)
+    assert rel(got.float(), K.gemm(x, w, a2=t, b2=b2, alpha2=0.5, bias=bias, residual=res).float()) < 4e-3
+    # strided output / input rows
+    big = torch.zeros(M, N + 24, dtype=torch.bfloat16, device=dev)
+    K.gemv(x, w, out=big[:, 8:8 + N])
+    assert rel(big[:, 8:8 + N].float(), base) < 4e-3 and big[:, :8].abs().sum() == 0 and big[:, 8 + N:].abs().sum() == 0
+
+
 def _sample(batch, b):
     """sample b alone, cut to its valid length (the reference generates one unpadded sample at a time)"""
     vi = batch['vlm_inputs']
@@ -167,3 +193,21 @@ def test_forward_with_past_key_values_like_the_reference_calls_it(dev, lm):
     assert step.logits.shape == (1, 1, lm.config.vocab_size)
     ref = lm.generate(**kw, **img, forced_tokens=torch.tensor([[tok.bop_token_id, 5]], device=dev), return_logits=True)
     assert torch.equal(step.logits[:, 0], ref.logits[1])
+
+
+def test_graph_replayed_decode_equals_eager(dev, lm):
+    """the hipGraph-captured decode step (static buffers, device-side step counter) reproduces the eager loop bit for bit"""
+    batch, tok = make_inputs(dev)
+    lm.tokenizer = tok
+    vi = batch['vlm_inputs']
+    kw = dict(token_type_ids=vi['token_type_ids'], position_ids=vi['position_ids'], attention_mask=vi['attention_mask'],
+              image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
+    eager = lm.generate(vi['input_ids'], **kw, max_new_tokens=12)
+    graphed = lm.generate(vi['input_ids'], **kw, max_new_tokens=12, use_graph=True)
+    assert torch.equal(eager.new_tokens, graphed.new_tokens) and torch.equal(eager.new_position_ids, graphed.new_position_ids)
+    assert graphed.past_key_values.lens.tolist() == eager.past_key_values.lens.tolist()
+    eos = int(eager.new_tokens[0, 2])
+    a = lm.generate(vi['input_ids'], **kw, max_new_tokens=12, eos_token_id=eos, eos_check_every=4)
+    b = lm.generate(vi['input_ids'], **kw, max_new_tokens=12, eos_token_id=eos, eos_check_every=4, use_graph=True)
+    assert torch.equal(a.new_tokens, b.new_tokens)
+    assert (a.new_tokens[0, 2:] == eos).all()
