@@ -336,7 +336,7 @@ int vm_gemv_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const v
  * query of the one new token of sample b, whose own K / V row has already been appended (kv_lens counts it).
  * out[b * ldo + h * head_dim + d] = softmax_t(bf16(bf16(q * scale) . k_t)) . v_t, fp32 softmax. head_dim 32 / 64 / 128.
  * max_len: host-side upper bound of kv_lens (sizes the launch; no device->host sync). Two launches: per-chunk partials
- * (one wave per sample x head x 128 keys) and their merge; workspace from vm_attn_decode_workspace. Deterministic. */
+ * (one wave per sample x head x 32 keys) and their merge; workspace from vm_attn_decode_workspace. Deterministic. */
 int vm_attn_decode_workspace(int batch, int n_heads, int head_dim, int max_len, int64_t* bytes_host);
 int vm_attn_decode_bf16(const void* q, int64_t ldq, const void* k_cache, const void* v_cache, int64_t ld_row, int64_t ld_seq,
                         const int32_t* kv_lens_dev, void* out, int64_t ldo, int batch, int n_heads, int head_dim, int max_len,

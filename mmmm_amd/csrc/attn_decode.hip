@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int DEC_CHUNK = 128;     // keys per wave
+constexpr int DEC_CHUNK = 32;      // keys per wave: a 500-token context of ONE sample still gives 16 x n_heads waves
 
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
@@ -58,17 +58,26 @@ __global__ __launch_bounds__(64) void attn_decode_k(const unsigned short* __rest
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int r0 = k0; r0 < k1; r0 += RPL) {
-    const int r = r0 + rsel;
-    const bool live = r < k1;
-    u16x8_t kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) {
-      kv = *reinterpret_cast<const u16x8_t*>(kb + (int64_t)r * ld_row);
-      vv = *reinterpret_cast<const u16x8_t*>(vb + (int64_t)r * ld_row);
+  // the whole chunk is requested before anything is consumed: NLOAD K rows and NLOAD V rows per lane in flight
+  constexpr int NLOAD = DEC_CHUNK / RPL;
+  u16x8_t kv[NLOAD], vv[NLOAD];
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int r = k0 + i * RPL + rsel;
+    kv[i] = vv[i] = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < k1) {
+      kv[i] = *reinterpret_cast<const u16x8_t*>(kb + (int64_t)r * ld_row);
+      vv[i] = *reinterpret_cast<const u16x8_t*>(vb + (int64_t)r * ld_row);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int r0 = k0 + i * RPL;
+    if (r0 >= k1) break;                                                 // wave-uniform
+    const bool live = r0 + rsel < k1;
     float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s = fmaf(qf[e], bf2f(kv[e]), s);
+    for (int e = 0; e < 8; ++e) s = fmaf(qf[e], bf2f(kv[i][e]), s);
 #pragma unroll
     for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);       // every lane of the row group holds the score
     s = live ? bf2f(f2bf(s)) : -INFINITY;
@@ -76,12 +85,12 @@ __global__ __launch_bounds__(64) void attn_decode_k(const unsigned short* __rest
     float mx = s;
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    const float m_new = fmaxf(m, mx);                                    // finite: at least one row of the load is live
+    const float m_new = fmaxf(m, mx);                                    // finite: row r0 is live
     const float corr = __expf(m - m_new);                                // m == -inf on the first load -> 0
     const float p = live ? __expf(s - m_new) : 0.f;
     l = l * corr + p;                                                    // per row group; groups are summed at the end
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, bf2f(vv[e]), acc[e] * corr);
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, bf2f(vv[i][e]), acc[e] * corr);
     m = m_new;
   }
   // fold the RPL row groups (lanes with equal `sub`)
@@ -98,21 +107,37 @@ __global__ __launch_bounds__(64) void attn_decode_k(const unsigned short* __rest
   }
 }
 
-// merge the chunk partials of one (sample, head): one thread per output element
+// merge the chunk partials of one (sample, head): one thread per output element. The chunk weights are computed once,
+// cooperatively, into LDS (one independent load per thread instead of a dependent chain of 2 * n_chunks loads per thread).
+constexpr int MERGE_MAX_CHUNKS = 1024;
 __global__ void attn_decode_merge_k(const float* __restrict__ part, unsigned short* __restrict__ out, int64_t ldo, int n_heads,
                                     int n_chunks, int hd) {
+  __shared__ float wgt[MERGE_MAX_CHUNKS];
+  __shared__ float red[2];
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-  if (d >= hd) return;
-  const float* p = part + ((int64_t)b * n_heads + h) * n_chunks * (hd + 2);
+  const int stride = hd + 2;
+  const float* p = part + ((int64_t)b * n_heads + h) * n_chunks * stride;
+  // every thread walks the same chunk list for the maximum (n_chunks is small); the loads are independent
   float m = -INFINITY;
-  for (int c = 0; c < n_chunks; ++c) m = fmaxf(m, p[c * (hd + 2)]);
+  for (int c = d; c < n_chunks; c += blockDim.x) m = fmaxf(m, p[c * stride]);
+  // block maximum through LDS atomics-free: wave shuffles then one slot per wave (blockDim <= 128 -> 2 waves)
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((d & 63) == 0) red[d >> 6] = m;
+  __syncthreads();
+  m = blockDim.x > 64 ? fmaxf(red[0], red[1]) : red[0];
+  for (int c = d; c < n_chunks; c += blockDim.x) {
+    const float lc = p[c * stride + 1];
+    wgt[c] = lc > 0.f ? __expf(p[c * stride] - m) : 0.f;        // empty chunk: weight 0, accumulator slots never written
+  }
+  __syncthreads();
+  if (d >= hd) return;
   float l = 0.f, o = 0.f;
+#pragma unroll 4
   for (int c = 0; c < n_chunks; ++c) {
-    const float* pc = p + c * (hd + 2);
-    if (!(pc[1] > 0.f)) continue;                  // empty chunk: its accumulator slots were never written
-    const float w = __expf(pc[0] - m);
-    l += w * pc[1];
-    o += w * pc[2 + d];
+    const float w = wgt[c];
+    if (w == 0.f) continue;
+    l += w * p[c * stride + 1];
+    o += w * p[c * stride + 2 + d];
   }
   out[(int64_t)b * ldo + h * hd + d] = f2bf(l > 0.f ? o / l : 0.f);   // an empty cache row set gives zeros
 }
@@ -141,6 +166,7 @@ int vm_attn_decode_bf16(const void* q, int64_t ldq, const void* k_cache, const v
   vm_attn_decode_workspace(batch, n_heads, head_dim, max_len, &need);
   if (workspace_bytes < need) return VM_ERR_BAD_ARG;
   const int n_chunks = (max_len + DEC_CHUNK - 1) / DEC_CHUNK;
+  if (n_chunks > MERGE_MAX_CHUNKS) return VM_ERR_UNSUPPORTED;          // 32k tokens
   const dim3 grid(n_chunks, n_heads, batch);
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *qp = (const unsigned short*)q, *kp = (const unsigned short*)k_cache, *vp = (const unsigned short*)v_cache;
@@ -148,7 +174,7 @@ int vm_attn_decode_bf16(const void* q, int64_t ldq, const void* k_cache, const v
   if (head_dim == 128) hipLaunchKernelGGL(attn_decode_k<16>, grid, dim3(64), 0, st, qp, ldq, kp, vp, ld_row, ld_seq, kv_lens_dev, part, n_heads, n_chunks, scale);
   else if (head_dim == 64) hipLaunchKernelGGL(attn_decode_k<8>, grid, dim3(64), 0, st, qp, ldq, kp, vp, ld_row, ld_seq, kv_lens_dev, part, n_heads, n_chunks, scale);
   else hipLaunchKernelGGL(attn_decode_k<4>, grid, dim3(64), 0, st, qp, ldq, kp, vp, ld_row, ld_seq, kv_lens_dev, part, n_heads, n_chunks, scale);
-  hipLaunchKernelGGL(attn_decode_merge_k, dim3(n_heads, batch), dim3(head_dim), 0, st, part, (unsigned short*)out, ldo, n_heads, n_chunks, head_dim);
+  hipLaunchKernelGGL(attn_decode_merge_k, dim3(n_heads, batch), dim3(head_dim < 64 ? 64 : head_dim), 0, st, part, (unsigned short*)out, ldo, n_heads, n_chunks, head_dim);
   return hipGetLastError() == hipSuccess ? VM_OK : VM_ERR_LAUNCH;
 }
 

@@ -162,7 +162,9 @@ def linear_decode(x: torch.Tensor, lin: Linear, residual: torch.Tensor | None = 
     (`vm_gemv_bf16`) when the shape allows, else by the tiled GEMM"""
     t = None
     if lin.lora_cfg is not None:
-        t = Fh._lora_project(x, lin.A, None, False, None)
+        # t = x A^T: the rank-64 factor is itself a skinny linear (one launch; the split-K down-projection kernel of the
+        # training path is two launches sized for thousands of rows)
+        t = K.gemv(x, lin.A) if K.gemv_supported(x, lin.A) else Fh._lora_project(x, lin.A, None, False, None)
     scale = lin.lora_cfg.scale if lin.lora_cfg is not None else 1.0
     if K.gemv_supported(x, lin.weight, t):
         return K.gemv(x, lin.weight, a2=t, b2=lin.B, alpha2=scale, bias=lin.bias, residual=residual)

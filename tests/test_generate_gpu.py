@@ -36,7 +36,7 @@ def ref_decode_attention(q, kc, vc, lens, H, hd, scale):
 def test_attn_decode_kernel(dev, K, hd):
     g = torch.Generator().manual_seed(hd)
     B, H, Lmax = 5, 3, 400
-    lens = torch.tensor([1, 127, 128, 129, 400], dtype=torch.int32)
+    lens = torch.tensor([1, 32, 33, 129, 400], dtype=torch.int32)      # chunk edges (32 keys per wave)
     q = torch.randn(B, 3 * H * hd, generator=g).bfloat16()[:, :H * hd]          # strided rows, like the q third of a packed qkv
     kc = torch.randn(B, Lmax, H * hd, generator=g).bfloat16()
     vc = torch.randn(B, Lmax, H * hd, generator=g).bfloat16()
