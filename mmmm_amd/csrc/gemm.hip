@@ -352,24 +352,32 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
   return VM_OK;
 }
 
-extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, void* stream);
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, void* stream);
 
 // Tile choice by estimated rounds over the 256 CUs. Measured on MI355X (tools/bench_gemm_vit.py): one round of 256x256
 // tiles (1 workgroup per CU) costs about 3.0x one round-equivalent of 128x128 tiles (2 co-resident workgroups per CU
-// retire 256 tiles per unit), so 256x256 wins whenever ceil(T256/256) * 3 <= ceil(T128/256).
-// VM_GEMM_TILE=128|256 forces a choice (tests / A-B measurements).
-static bool use_tile256(int M, int N, int K, bool segmented) {
+// retire 256 tiles per unit), so 256x256 wins whenever ceil(T256/256) * 3 <= ceil(T128/256). Between the 256-row and the
+// 192-row form of the big tile (same kernel, 16 vs 12 MFMAs per phase: a round of 192-row tiles costs ~0.78 of a round of
+// 256-row ones) the cheaper rounds x cost wins: [6280 x 1792] 1 x 1.0 vs 1 x 0.78, [6280 x 5376] 3 x 1.0 vs 3 x 0.78,
+// [6280 x 15360] 6 x 1.0 vs 8 x 0.78.
+// Returns 0 (128x128 tiles), 256 or 192. VM_GEMM_TILE=128|192|256 forces a choice, -192 only removes the 192-row form
+// from the automatic choice (tests / A-B measurements).
+static int big_tile_rows(int M, int N, int K, bool segmented) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("VM_GEMM_TILE");
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 128) return false;
-  if (forced == 256) return true;
-  if (K < 128) return false;
-  const int64_t t256 = (int64_t)((M + 255) / 256 + (segmented ? 1 : 0)) * ((N + 255) / 256);
+  if (forced == 128) return 0;
+  if (forced == 256 || forced == 192) return forced;
+  if (K < 128) return 0;
+  const int64_t tn = (N + 255) / 256;
+  const int64_t t256 = (int64_t)((M + 255) / 256 + (segmented ? 1 : 0)) * tn;
+  const int64_t t192 = (int64_t)((M + 191) / 192 + (segmented ? 1 : 0)) * tn;
   const int64_t t128 = (int64_t)((M + 127) / 128 + (segmented ? 1 : 0)) * ((N + 127) / 128);
-  return ((t256 + 255) / 256) * 3 <= (t128 + 255) / 256;
+  const int64_t r256 = (t256 + 255) / 256, r192 = (t192 + 255) / 256, r128 = (t128 + 255) / 256;
+  if (r256 * 3 > r128) return 0;
+  return (forced != -192 && r192 * 78 < r256 * 100) ? 192 : 256;
 }
 
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
@@ -423,8 +431,9 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
-  if (esz == 2 && p.ksplit <= 1 && use_tile256(a->M, a->N, a->K + a->K2, segmented)) {
-    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, stream);
+  const int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
+  if (big) {
+    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, stream);
     if (rc != VM_OK) return rc;
   } else if (esz == 4 && bm64)
     hipLaunchKernelGGL((gemm_nt_k<4, true, 64>), dim3(grid, 1), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);

@@ -23,9 +23,12 @@ constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
 constexpr int STAGE_BYTES2 = 4 * HALF_BYTES;
 constexpr int LDS_BYTES2 = 2 * STAGE_BYTES2;
 
-// LDS-DMA of one half-tile: 16 wave-instructions of 1 KiB (8 rows), 2 per wave. KIND 0: activation (A-h{half}),
-// row r -> tile row (r>>6)*128 + half*64 + (r&63); KIND 1: weight (B-h{half}), r -> (r>>5)*64 + half*32 + (r&31).
-template <int KIND>
+// LDS-DMA of one half-tile: 16 wave-instructions of 1 KiB (8 rows), 2 per wave. KIND 0: activation (A-h{half}); with MI
+// 16-row fragments per wave and half (MI = 4: 256-row tile, MI = 3: 192-row tile) LDS row r -> tile row
+// (r / (16 MI)) * 32 MI + half * 16 MI + r % (16 MI); the LDS rows past 32 MI (MI = 3: the last 4 instructions) are issued
+// with an out-of-range offset — zero fill, no memory traffic — so every wave still issues two loads and the counted
+// vmcnt waits stay uniform. KIND 1: weight (B-h{half}), r -> (r>>5)*64 + half*32 + (r&31).
+template <int KIND, int MI = 4>
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_bytes, int koff, int half, char* lds_half,
                                            int wave, int lane) {
   const int r8 = lane >> 3, slot = lane & 7;
@@ -34,8 +37,15 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_b
   for (int i = 0; i < 2; ++i) {
     const int inst = wave * 2 + i;
     const int r = inst * 8 + r8;
-    const int trow = KIND == 0 ? ((r >> 6) * 128 + half * 64 + (r & 63)) : ((r >> 5) * 64 + half * 32 + (r & 31));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_half + inst * 1024), 16, trow * ld_bytes + chunk * 16, koff, 0, 0);
+    int voff;
+    if (KIND == 0) {
+      constexpr int HR = 16 * MI;                 // rows of one wave-row inside a half
+      const int trow = (r / HR) * (2 * HR) + half * HR + r % HR;
+      voff = (MI == 4 || r < 2 * HR) ? trow * ld_bytes + chunk * 16 : 0x40000000;
+    } else {
+      voff = ((r >> 5) * 64 + half * 32 + (r & 31)) * ld_bytes + chunk * 16;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_half + inst * 1024), 16, voff, koff, 0, 0);
   }
 }
 
@@ -50,16 +60,18 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_b
 
 // epilogue shared by the two 256x256 kernels: accumulators -> (bias, residual) -> C. Every wave must have passed its last
 // LDS read (the staging memory is reused for the per-wave output slabs).
-template <bool OUT_F32>
-__device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[8][4], char* smem, int wave, int lane, int wm, int wn,
+template <bool OUT_F32, int MI>
+__device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[2 * MI][4], char* smem, int wave, int lane, int wm, int wn,
                                             int row0, int nrows, int n0, int ncols, int seg) {
+  constexpr int WR = 32 * MI;          // rows of one wave-row (128 or 96)
+  constexpr int HR = 16 * MI;          // rows of one slab pass
   const int frow = lane & 15, fq = lane >> 4;
   if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ml = wm * 128 + i * 16 + frow;
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int ml = wm * WR + i * 16 + frow;
       if (ml >= nrows) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -69,8 +81,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
       }
     }
   } else {
-    // every wave has passed the final barrier: LDS is free. 64 x 64 slab per wave, two passes (upper / lower 64 rows).
-    typedef EpiSlab<64, 64> Slab;
+    // every wave has passed the final barrier: LDS is free. (16 MI) x 64 slab per wave, two passes (upper / lower rows).
+    typedef EpiSlab<HR, 64> Slab;
     char* slab = smem + wave * Slab::BYTES;
     const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
     const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 64 >= 64 && ((uintptr_t)bias & 7) == 0;
@@ -83,32 +95,37 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
     for (int half = 0; half < 2; ++half) {
       if (fast_bias) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j], bv[j]);
+            epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * MI + i][j], bv[j]);
       } else if (plain) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * 4 + i][j]);
+            epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, acc[half * MI + i][j]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int nl = wn * 64 + j * 16 + fq * 4;
-            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * 4 + i][j]);
+            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[half * MI + i][j]);
           }
       }
-      epi_flush<64, 64>(slab, p, row0 + wm * 128 + half * 64, n0 + wn * 64, nrows - wm * 128 - half * 64, ncols - wn * 64, lane);
+      epi_flush<HR, 64>(slab, p, row0 + wm * WR + half * HR, n0 + wn * 64, nrows - wm * WR - half * HR, ncols - wn * 64, lane);
     }
   }
 }
 
-template <bool OUT_F32>
+// MI = 16-row activation fragments per wave and half: 4 -> 256 x 256 tile, 3 -> 192 x 256 tile (same LDS image, same phase
+// structure, 12 instead of 16 MFMAs per phase). The 192-row tile exists for tile-count quantisation: [6280 x 1792] is 175
+// tiles of 256 rows (68 % of one round over 256 CUs) but 231 tiles of 192 rows, [6280 x 5376] is 525 (3 rounds) vs 693
+// (3 rounds of 0.75 the work).
+template <bool OUT_F32, int MI>
 __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
+  constexpr int BMT = 64 * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   int tm, tn;
   gemm_tile_id(p, tm, tn);
   int row0, nrows, seg;
-  gemm_tile_rows<256>(p, tm, row0, nrows, seg);
+  gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
   if (nrows <= 0) return;
   const int n0 = tn * 256;
   const int ncols = min(256, p.N - n0);
@@ -142,16 +159,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     char* dst = smem + (t & 1) * STAGE_BYTES2 + h * HALF_BYTES;
     const bool ext = t < kt_ext;
     const int koff = (ext ? t : t - kt_ext) * 128;
-    if (h < 2) stage_half<0>(ext ? rA2 : rA, ext ? lda2_b : lda_b, koff, h, dst, wave, lane);
+    if (h < 2) stage_half<0, MI>(ext ? rA2 : rA, ext ? lda2_b : lda_b, koff, h, dst, wave, lane);
     else stage_half<1>(ext ? rB2 : rB, ext ? ldb2_b : ldb_b, koff, h - 2, dst, wave, lane);
   };
 
-  f32x4_t acc[8][4];   // [m-tile of the wave's 128 rows][n-tile of its 64 columns]
+  f32x4_t acc[2 * MI][4];   // [m-tile of the wave's 32 MI rows][n-tile of its 64 columns]
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t aF[4][2];       // activation fragments of the current m-half: [m-tile][k-substep]
+  bf16x8_t aF[MI][2];      // activation fragments of the current m-half: [m-tile][k-substep]
   bf16x8_t bF[2][2][2];    // weight fragments: [n-half][n-tile][k-substep]
 
   const int frow = lane & 15, fq = lane >> 4;
@@ -159,10 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   const int off_k0 = frow * 128 + slot0 * 16;
   const int off_k1 = frow * 128 + (slot0 ^ 4) * 16;
 
-  auto read_a = [&](const char* st, int mh) {   // wave's rows of A-h{mh}: wm*64 + i*16 + frow
-    const char* base = st + mh * HALF_BYTES + (wm * 64) * 128;
+  auto read_a = [&](const char* st, int mh) {   // wave's rows of A-h{mh}: wm*16*MI + i*16 + frow
+    const char* base = st + mh * HALF_BYTES + (wm * 16 * MI) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       aF[i][0] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048 + off_k0);
       aF[i][1] = *reinterpret_cast<const bf16x8_t*>(base + i * 2048 + off_k1);
     }
@@ -179,10 +196,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[nh][j][ks], aF[i][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+          acc[mh * MI + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[nh][j][ks], aF[i][ks], acc[mh * MI + i][nh * 2 + j], 0, 0, 0);
   };
 
   // Wave rows are STAGGERED by one barrier interval: the two waves that share a SIMD (wave w and w+4, i.e. wm = 0
@@ -234,13 +251,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   auto ext_scale = [&]() {
     if (p.drop_p > 0.f) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          gemm_ext_scale4<true>(p, row0 + wm * 128 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+          gemm_ext_scale4<true>(p, row0 + wm * 32 * MI + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] *= p.alpha2;
     }
@@ -267,24 +284,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #endif
 
-  epilogue256<OUT_F32>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
+  epilogue256<OUT_F32, MI>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
 }
 
 }  // namespace
 
 // called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles
-extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, void* stream) {
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, void* stream) {
   GemmParams p = *(const GemmParams*)params;
-  p.tiles_m = (p.M + 255) / 256 + (segmented ? 1 : 0);
+  if (tile_rows != 256 && tile_rows != 192) return VM_ERR_BAD_ARG;
+  p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
   p.tiles_n = (p.N + 255) / 256;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm256_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
+    const void* fns[4] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+                          (const void*)gemm256_k<true, 3>};
+    for (const void* f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
     attr_set = true;
   }
-  const int grid = p.tiles_m * p.tiles_n;
-  if (out_f32) hipLaunchKernelGGL(gemm256_k<true>, dim3(grid), dim3(512), LDS_BYTES2, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gemm256_k<false>, dim3(grid), dim3(512), LDS_BYTES2, (hipStream_t)stream, p);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (tile_rows == 256) {
+    if (out_f32) hipLaunchKernelGGL((gemm256_k<true, 4>), grid, block, LDS_BYTES2, st, p);
+    else hipLaunchKernelGGL((gemm256_k<false, 4>), grid, block, LDS_BYTES2, st, p);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((gemm256_k<true, 3>), grid, block, LDS_BYTES2, st, p);
+    else hipLaunchKernelGGL((gemm256_k<false, 3>), grid, block, LDS_BYTES2, st, p);
+  }
   return VM_OK;
 }

@@ -45,6 +45,21 @@ def test_gemm_bf16_plain(dev, K, M, N, K_):
     assert max_err(out, ref.bfloat16()) <= 2 ** -6 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize('tile', ['192', '256'])
+def test_gemm_bf16_suite_with_forced_big_tiles(dev, tile):
+    """the tile chooser picks the 256-row / 192-row big-tile kernels only for shapes that fill the chip; VM_GEMM_TILE (read
+    once per process) forces them, so the bf16 GEMM tests are re-run in a child process on every small / ragged shape too"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('VM_TEST_CHILD'):
+        pytest.skip('already inside the forced-tile child')
+    env = dict(os.environ, VM_GEMM_TILE=tile, VM_TEST_CHILD='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-m', 'gpu', '-q', '-x', '-k', 'gemm_bf16 and not forced'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_gemm_bf16_asymmetric_identity(dev, K):
     # A = I check with an asymmetric B: catches row/col swaps in the C write
     n = 128
