@@ -301,8 +301,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
 // O[c][n] = sum_m W[m][c] * S[m][n] with a WIDE streamed operand W [M, C] and a rank-64 operand S [M, 64]:
 //   dB[N, 64] = s * dy^T t      (W = dy, S = t)            -> out[c][n]
 //   dA[64, K] = s * u^T drop(x) (W = x with the forward's LoRA dropout mask, S = u) -> out[n][c] (transpose_out)
-// A workgroup owns 64 columns of W and a range of rows; 32-row steps run through a 4-stage LDS-DMA ring (three steps of
-// loads in flight, one barrier per step). Row-range partial sums go to an fp32 workspace and tn_reduce_k adds them in a
+// A workgroup owns 64 columns of W and a range of rows; 32-row steps run through an LDS-DMA ring (SK_STAGES - 1 steps of
+// loads in flight, one barrier per step). Two stages = 32 KiB: measured as fast as four in isolation (4.8 vs 4.6 TB/s on
+// [6280 x 15360]; several workgroups per CU hide the latency instead) and small enough to sit beside a 128 KiB workgroup
+// of the 256x256 GEMM on the same CU, which matters because these kernels run on the side stream under the dgrad GEMMs. Row-range partial sums go to an fp32 workspace and tn_reduce_k adds them in a
 // fixed order, scales, optionally accumulates into the existing gradient and writes bf16 / fp32 (deterministic: no
 // atomics, no pre-zeroed buffer, no separate cast).
 struct SkP {
@@ -316,7 +318,10 @@ struct SkP {
   float drop_p; uint64_t seed;
 };
 constexpr int SK_STAGE = 2 * 32 * ROWB;
-constexpr int SK_STAGES = 4;
+#ifndef VM_SK_STAGES
+#define VM_SK_STAGES 2
+#endif
+constexpr int SK_STAGES = VM_SK_STAGES;     // ring depth: SK_STAGES - 1 steps of loads in flight (4 DMA instructions per wave and step)
 
 // BC = 64: waves as 2 (c) x 2 (n), one 32x32 accumulator each — many small tiles for narrow W (C of a few thousand);
 // BC = 128: wave w owns columns 32w..32w+31 and both n halves — full 256-byte row segments for wide W.
@@ -361,12 +366,15 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
   const unsigned thr = vm_drop_threshold(p.drop_p);
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
-  stage(s_begin, 0); stage(s_begin + 1, 1); stage(s_begin + 2, 2);
+#pragma unroll
+  for (int i = 0; i < SK_STAGES - 1; ++i) stage(s_begin + i, i);
   for (int st = s_begin; st < s_end; ++st) {
-    const int buf = (st - s_begin) & 3;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's part of step `st` has landed (2 steps stay in flight)
+    const int buf = (st - s_begin) % SK_STAGES;
+    if (SK_STAGES == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's part of step `st` has landed (2 steps stay in flight)
+    else if (SK_STAGES == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // ... everybody's has, and step st-1 has been consumed
-    stage(st + 3, (buf + 3) & 3);
+    stage(st + SK_STAGES - 1, (buf + SK_STAGES - 1) % SK_STAGES);
     char* sw = smem + buf * SK_STAGE;
     const char* ss = sw + 32 * ROWB;
     if (drop) {
