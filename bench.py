@@ -210,8 +210,8 @@ def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
     ap.add_argument('--depth-scale', type=float, default=1.0, help='debug only: <1 shrinks depth and invalidates the number')

@@ -320,6 +320,15 @@ typedef struct vm_attn_args {
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
 
+/* Rectangular linear sum assignment (Hungarian matching) of many small cost matrices on the device:
+ * InstanceSamLoss._match_instances, segvol/modeling/sam.py:243 (`scipy.optimize.linear_sum_assignment` on the host in the
+ * reference: one device->host synchronisation per target). cost[p * ld_prob + r * ld_row + c], fp32, solved in double by the
+ * algorithm SciPy uses (Crouse 2016) with its scan order and tie rule: the result equals SciPy's. dims_dev[2p], [2p+1] =
+ * rows, cols of problem p (rows <= cols <= 64; rows == 0 marks a padding entry); col4row[p * ld_out + r] = assigned
+ * column of row r. max_cols: host upper bound of the column counts (> 64 -> VM_ERR_UNSUPPORTED, solve on the host). */
+int vm_lsap_f32(const float* cost, int64_t ld_prob, int64_t ld_row, const int32_t* dims_dev, int32_t* col4row,
+                int64_t ld_out, int n_prob, int max_cols, void* stream);
+
 /* Skinny-M linear of the decode step (one row per sample): out[M,N] = x[M,K] W[N,K]^T + alpha2 * x2[M,K2] W2[N,K2]^T
  * + bias[N], then (rounded to bf16) + residual[M,N] — the language-expert nn.Linear calls of
  * modeling_cogvlm.py:243-245, 277-279, 54-56 and lm_head (:706) when L == 1. bf16 operands, fp32 accumulation.

@@ -465,6 +465,20 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *
              dtype_code(p.dtype), stream())
 
 
+# ------------------------------------------------------------------ Hungarian matching
+LSAP_MAX_COLS = 64
+
+
+def lsap(cost: torch.Tensor, dims: torch.Tensor, max_cols: int) -> torch.Tensor:
+    """cost fp32 [P, R, C] (padded), dims int32 [P, 2] = (rows, cols) of each problem (rows <= cols <= 64; rows 0 = padding
+    entry) -> int32 [P, R]: column assigned to each row, identical to scipy.optimize.linear_sum_assignment"""
+    assert cost.dtype == torch.float32 and cost.dim() == 3 and cost.stride(2) == 1 and dims.dtype == torch.int32
+    P, R, _ = cost.shape
+    out = torch.full((P, R), -1, dtype=torch.int32, device=cost.device)
+    hip.call('vm_lsap_f32', ptr(cost), cost.stride(0), cost.stride(1), ptr(dims), ptr(out), out.stride(0), P, int(max_cols), stream())
+    return out
+
+
 # ------------------------------------------------------------------ generation path
 @functools.lru_cache(maxsize=64)
 def _attn_decode_ws_bytes(batch: int, n_heads: int, head_dim: int, max_len: int) -> int:

@@ -239,7 +239,7 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         """mmmm.py:225-285"""
         B = len(masks_logits)
         loss_list, log_dict = [], {}
-        # Hungarian matching of all instance samples with one device->host transfer
+        # Hungarian matching of all instance samples, solved on the device (no device->host synchronisation)
         inst = [i for i in range(B) if boxes_label[i] is not None and masks_label[i] is None and disc_logit[i].shape[0] > 0]
         matches = dict(zip(inst, self.isam_loss.match_samples(
             [(boxes_reg[i], disc_logit[i], boxes_label[i], index_offsets[i]) for i in inst]))) if inst else {}

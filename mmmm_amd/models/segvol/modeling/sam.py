@@ -12,6 +12,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from .... import functional as Fh
+from .... import kernels as K
 from ...lora import Linear
 from ...loss import DiceFocalLoss, sigmoid_focal_loss
 from .image_encoder import ImageEncoderViT
@@ -205,17 +206,22 @@ class InstanceSamLoss(nn.Module):
     @torch.no_grad()
     def match_samples(self, samples: list[tuple]) -> list[torch.Tensor]:
         """Hungarian matching of SEVERAL samples [(boxes_reg [nt, 1 + nq, 6], disc_logit [nt, nq], boxes_label, index_offsets
-        (host))] with ONE device->host transfer of all their cost matrices (one synchronisation per step instead of one per
-        instance sample)."""
+        (host))] -> per sample int64 [nt, nq] (index of the matched target box | MATCH_NEGATIVE).
+        On the GPU the assignment problems are solved where the costs are (`vm_lsap_f32`: SciPy's algorithm, SciPy's result)
+        and the match stays on the device: the step has NO device->host synchronisation. (The reference synchronises once per
+        target, sam.py:243.) CPU tensors, or a cost matrix wider than the kernel supports, take the reference's route: SciPy
+        on the host, one transfer for all samples."""
         built = []
         for boxes_reg, disc_logit, boxes_label, index_offsets in samples:
             offs = [tuple(x) for x in index_offsets.tolist()]
             built.append(self._match_costs(boxes_reg[:, 1:], disc_logit.float(), boxes_label, offs))
         flat = [c for costs, _ in built for c in costs]
+        width = max((c.shape[1] for c in flat), default=0)
+        rows = max((c.shape[0] for c in flat), default=0)
+        if flat and flat[0].is_cuda and width <= K.LSAP_MAX_COLS:
+            return self._assign_on_device(flat, built, samples, rows, width)
         host = None
         if flat:
-            width = max(c.shape[1] for c in flat)
-            rows = max(c.shape[0] for c in flat)
             host = torch.stack([F.pad(c, (0, width - c.shape[1], 0, rows - c.shape[0])) for c in flat]).cpu().numpy()
         out, k = [], 0
         for (costs, metas), (boxes_reg, disc_logit, _, _) in zip(built, samples):
@@ -225,14 +231,38 @@ class InstanceSamLoss(nn.Module):
             out.append(self._assign(part, metas, nt, nq))
         return out
 
-    def _match_all(self, boxes_reg, disc_logit, boxes_label, index_offsets_host: list[tuple[int, int]]):
-        costs, metas = self._match_costs(boxes_reg, disc_logit, boxes_label, index_offsets_host)
-        nt, nq = disc_logit.shape
-        host = []
-        if costs:
-            width = max(c.shape[1] for c in costs)
-            host = torch.stack([F.pad(c, (0, width - c.shape[1])) for c in costs]).cpu().numpy()   # ONE device->host transfer
-        return self._assign(host, metas, nt, nq)
+    @staticmethod
+    def _assign_on_device(flat, built, samples, rows: int, width: int) -> list[torch.Tensor]:
+        """device counterpart of `_assign`: all problems of all samples in one `vm_lsap_f32` launch; the bookkeeping of
+        `_assign` (columns past the real targets -> MATCH_NEGATIVE, real ones shifted by the target's box offset) as a few
+        tensor ops driven by ONE small metadata upload"""
+        dev = flat[0].device
+        cost = torch.stack([F.pad(c, (0, width - c.shape[1], 0, rows - c.shape[0])) for c in flat])
+        meta, dims, row0 = [], [], 0
+        for (costs, metas), (_, disc_logit, _, _) in zip(built, samples):
+            nt, nq = disc_logit.shape
+            for i, m in enumerate(metas):
+                if m is not None:
+                    _, npos, ncol, off = m
+                    meta.append((row0 + i, npos, off))
+                    dims.append((nq, ncol))
+            row0 += nt
+        nq = samples[0][1].shape[1]
+        assert all(s[1].shape[1] == nq for s in samples)
+        packed = torch.tensor([(*a, *b) for a, b in zip(meta, dims)], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        col = K.lsap(cost, packed[:, 3:5].to(torch.int32).contiguous(), width)[:, :nq].long()
+        npos, off = packed[:, 1:2], packed[:, 2:3]
+        m = torch.where(col >= npos, torch.full_like(col, MATCH_NEGATIVE), col + off)
+        match = torch.full((row0, nq), MATCH_NEGATIVE, dtype=torch.int64, device=dev)
+        match.index_copy_(0, packed[:, 0], m)
+        out, row0 = [], 0
+        for _, disc_logit, _, _ in samples:
+            out.append(match[row0:row0 + disc_logit.shape[0]])
+            row0 += disc_logit.shape[0]
+        return out
+
+    def _match_all(self, boxes_reg_full, disc_logit, boxes_label, index_offsets):
+        return self.match_samples([(boxes_reg_full, disc_logit, boxes_label, index_offsets)])[0]
 
     def compute_loss(self, masks_logits, masks_logits_ds, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets, match=None):
         """reference :252-361, branch used by the training step (no instance masks)"""
@@ -243,20 +273,33 @@ class InstanceSamLoss(nn.Module):
         loss = 0 * disc_logit.sum()
         log = {}
         if nt > 0:
+            if match is None:
+                match = self._match_all(boxes_reg, disc_logit, boxes_label, index_offsets)      # int64 [nt, nq]
             boxes_reg = boxes_reg[:, 1:]
             disc_logit = disc_logit.float()
-            offs = [tuple(x) for x in index_offsets.tolist()]       # (host tensor when the step pre-copied it: no sync)
-            if match is None:
-                match = self._match_all(boxes_reg, disc_logit, boxes_label, offs)      # HOST int64 [nt, nq]
             dev = disc_logit.device
-            # the assignment lives on the host: turn its masks into index tensors there (async upload) instead of
-            # boolean-mask indexing on the device, which synchronises once per mask
-            up = lambda t: t.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else t
             flat = match.flatten()
-            pos_i, neg_i, cert_i = (m.nonzero().flatten() for m in (flat >= 0, flat == MATCH_NEGATIVE, flat != MATCH_UNCERTAIN))
+            if match.is_cuda:
+                # the assignment lives on the device and nothing may synchronise: which entries are positive is data, HOW
+                # MANY is not — a target with n > 0 boxes always matches min(n, nq) queries (the dummy negative columns only
+                # fill the square) — so the index tensors have host-known sizes. A stable sort keeps the entry order that
+                # boolean-mask indexing would give, so every mean below sums in the reference's order.
+                nq = disc_logit.shape[1]
+                n_pos = sum(min(e - s, nq) for s, e in (tuple(x) for x in index_offsets.tolist()) if e > s)
+                is_pos = flat >= 0
+                order = torch.argsort((~is_pos).to(torch.uint8), stable=True)
+                pos_i, neg_i, cert_i = order[:n_pos], order[n_pos:], None
+                up = lambda t: t
+                cert_label = is_pos
+            else:
+                # host assignment (CPU tensors): turn its masks into index tensors on the host
+                up = lambda t: t.pin_memory().to(dev, non_blocking=True) if dev.type == 'cuda' else t
+                pos_i, neg_i, cert_i = (m.nonzero().flatten() for m in (flat >= 0, flat == MATCH_NEGATIVE, flat != MATCH_UNCERTAIN))
+                n_pos = pos_i.numel()
+                cert_label = flat[cert_i] >= 0
             dflat = disc_logit.flatten()
-            n_pos = pos_i.numel()
-            d = self.disc_loss(dflat.index_select(0, up(cert_i)), up((flat[cert_i] >= 0)), return_dict=True)
+            # (no uncertain entries exist in this branch: on the device every entry is "certain")
+            d = self.disc_loss(dflat if cert_i is None else dflat.index_select(0, up(cert_i)), up(cert_label), return_dict=True)
             loss = loss + d.pop('total')
             log.update({f'instance-disc-{k}': v for k, v in d.items()})
             if n_pos > 0:
@@ -266,7 +309,7 @@ class InstanceSamLoss(nn.Module):
                     d.pop('total')
                     log.update({f'instance-disc-pos-{k}': v for k, v in d.items()})
                 d = self.box_loss(boxes_reg.reshape(-1, boxes_reg.shape[-1]).index_select(0, pos_d),
-                                  boxes_label.index_select(0, up(flat[pos_i])), return_dict=True)
+                                  boxes_label.index_select(0, up(flat.index_select(0, pos_i) if match.is_cuda else flat[pos_i])), return_dict=True)
                 loss = loss + d.pop('total')
                 log.update({f'instance-box-{k}': v for k, v in d.items()})
             if n_pos < flat.numel():

@@ -621,3 +621,42 @@ def test_flat_adamw_with_clipping_matches_torch(dev, K, dt):
         for p, r in zip(mine, ref):
             assert rel_err(p, r) < (4e-3 if dt == torch.bfloat16 else 2e-6), it
     ddp.remove()
+
+
+def test_lsap_matches_scipy(dev, K):
+    """device Hungarian matching == scipy.optimize.linear_sum_assignment, bit-exact, ties included: random float costs,
+    small-integer costs (many optimal assignments), constant matrices, duplicated columns (the dummy negative columns of
+    InstanceSamLoss), ragged sizes in one launch, padding entries"""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(7)
+    R, C = 8, 16
+    probs, dims = [], []
+    for t in range(600):
+        nr = int(rng.integers(1, R + 1))
+        nc = int(rng.integers(nr, C + 1))
+        kind = t % 5
+        if kind == 0:
+            c = rng.random((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(np.float64)
+        elif kind == 2:
+            c = np.full((nr, nc), 0.5)
+        elif kind == 3:
+            c = rng.integers(0, 5, (nr, nc)) * 0.25
+            c[:, nc // 2:] = c[:, nc // 2:nc // 2 + 1]
+        else:
+            c = rng.standard_normal((nr, nc)) * 1e3
+        probs.append(c.astype(np.float32))
+        dims.append((nr, nc))
+    dims.insert(5, (0, 0)); probs.insert(5, np.zeros((1, 1), np.float32))          # padding entry
+    cost = torch.zeros(len(probs), R, C)
+    for i, c in enumerate(probs):
+        cost[i, :c.shape[0], :c.shape[1]] = torch.from_numpy(c)
+    got = K.lsap(cost.to(dev), torch.tensor(dims, dtype=torch.int32, device=dev), C).cpu()
+    for i, (c, (nr, nc)) in enumerate(zip(probs, dims)):
+        if nr == 0:
+            continue
+        row, col = linear_sum_assignment(c)
+        assert row.tolist() == list(range(nr))
+        assert got[i, :nr].tolist() == col.tolist(), (i, c, col, got[i])

@@ -150,8 +150,9 @@ def test_losses_match_oracle_and_hungarian_is_bit_exact(dev):
     dummy = br.new_empty((*br.shape[:2], 0, 0, 0))
     loss, log = il.compute_loss(dummy, dummy, br, dl, None, i['boxes_label'].to(dev), i['index_offsets'].to(dev))
     assert rel(loss, i['loss']) < 1e-5
-    match = il._match_all(br.detach()[:, 1:], dl.detach().float(), i['boxes_label'].to(dev), [tuple(x) for x in i['index_offsets'].tolist()])
-    assert torch.equal(match.cpu(), i['match'])
+    match = il._match_all(br.detach(), dl.detach(), i['boxes_label'].to(dev), i['index_offsets'])
+    assert match.is_cuda                                     # solved on the device: no device->host synchronisation
+    assert torch.equal(match.cpu(), i['match'])              # == the reference's SciPy assignment, bit-exact
     loss.backward()
     assert rel(br.grad, i['d_boxes']) < 1e-4 and rel(dl.grad, i['d_disc']) < 1e-4
     for k, v in i['log'].items():
