@@ -292,10 +292,12 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
+    ms1 = torch.cuda.memory_stats(device)
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -319,6 +321,10 @@ def main():
                        'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
                        'gradient_checkpointing': plan, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
+            # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
+            # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
+            'allocator': {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
+                         | {'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 2**30, 1)},
             'model_tflops_per_image': fl_sample / 1e12,
             'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,
         }
