@@ -39,6 +39,11 @@ WORKLOADS = {
                           desc='phase-vlm (sam=None) LoRA bf16, 2D 448x448, batch 8/GPU, CogVLM-7B'),
     'phase-grg-3d': dict(image=(3, 32, 256, 256), patch=(4, 16, 16), pool=(2, 2, 2), text=256, sam=True,
                          desc='BASELINE configs[3]: phase-grg 3D CT 32x256x256'),
+    # BASELINE configs[4] shapes (conf/model-hr.yaml; bf16 here — the reference has no fp8 path): parity / capacity cases
+    'model-hr-2d': dict(image=(3, 1, 896, 896), patch=(1, 16, 16), pool=(1, 2, 2), text=256, sam=True,
+                        desc='BASELINE configs[4]: high-res 2D 896x896 (3137 ViT tokens, 784 LM image tokens per sample)'),
+    'model-hr-3d': dict(image=(3, 64, 384, 384), patch=(8, 16, 16), pool=(2, 2, 2), text=256, sam=True,
+                        desc='BASELINE configs[4]: high-res 3D 64x384x384 (4609 ViT tokens, 576 LM image tokens per sample)'),
     # BASELINE configs[2]: per-rank batch = half 2D 448x448, half 3D 32x256x256, variable text length, sam=None
     'phase-vlm-mixed': dict(image=(3, 1, 448, 448), patch=(1, 16, 16), pool=(1, 2, 2), text=256, sam=False, mixed=True,
                             desc='BASELINE configs[2]: phase-vlm, mixed 2D 448x448 / 3D 32x256x256 batch, text 128..512, CogVLM-7B'),
