@@ -161,11 +161,25 @@ def ptr(t: torch.Tensor | None) -> int | None:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device. The raw accessor avoids building a torch.cuda.Stream
+    object per launch (9 us of host time each, ~5k launches per training step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_fns: dict = {}
 
 
 def call(name: str, *args):
     """Call a C-ABI entry point with raw arguments and raise on a non-zero status."""
-    fn = getattr(lib(), name)
-    check(fn(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)
