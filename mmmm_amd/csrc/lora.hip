@@ -109,9 +109,7 @@ __global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
         const int kk = kt * 128 + 32 * s + 8 * fq;
         const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
         const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)   // same rounding as the standalone dropout kernel: bf16(x * 1/(1-p))
-          xv[e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(xv[e]) * inv_keep) : (unsigned short)0;
+        vm_mask8(xv, h0, h1, thr);           // 1/(1-p) is applied to the accumulators below
       }
       const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv);
 #pragma unroll
@@ -125,6 +123,10 @@ __global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
   }
   // D[row = r][col = m_local]: lane holds r = 16 i + 4 fq + 0..3 for row m
   if (wave * 16 + frow >= nrows) return;
+  if (drop) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] *= inv_keep;
+  }
   if (p.ksplits > 1) {
     float* w = p.ws + ((int64_t)blockIdx.y * p.M + m) * 64;
 #pragma unroll
@@ -232,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
   };
   const bool drop = p.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(p.drop_p);
-  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
   if (s_begin < s_end) stage(s_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -254,9 +255,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
         u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
         const uint64_t idx = (uint64_t)(r0 + row) * (uint64_t)p.drop_cols + (uint64_t)col;
         const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(v[e]) * inv_keep) : (unsigned short)0;
+        vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
         *reinterpret_cast<u16x8_t*>(addr) = v;
       }
       __syncthreads();
@@ -364,7 +363,6 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
   };
   const bool drop = p.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(p.drop_p);
-  const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 
 #pragma unroll
   for (int i = 0; i < SK_STAGES - 1; ++i) stage(s_begin + i, i);
@@ -388,9 +386,7 @@ __global__ __launch_bounds__(256, 2) void tn_skinny_k(const SkP p) {
         u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
         const uint64_t idx = (uint64_t)(r0 + row) * (uint64_t)p.C + (uint64_t)col;
         const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] = vm_keep_bits(e < 4 ? h0 : h1, e & 3, thr) ? f2bf(bf2f(v[e]) * inv_keep) : (unsigned short)0;
+        vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
         *reinterpret_cast<u16x8_t*>(addr) = v;
       }
       __syncthreads();
@@ -536,7 +532,7 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
   p.nrows_dev = nrows_dev;
   p.splits = splits; p.out_f32 = out_dtype == VM_F32;
   p.drop_p = drop_p; p.seed = drop_seed; p.drop_cols = drop_cols;
-  p.alpha = alpha;
+  p.alpha = drop_p > 0.f ? alpha / (1.0f - drop_p) : alpha;      // the kernel only masks; inverted-dropout scale folded here
   p.tiles_p = (P + 127) / 128; p.tiles_q = (Q + 127) / 128;
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
@@ -575,6 +571,7 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
   if (workspace_bytes < (int64_t)nseg * p.splits * p.c_pad * 64 * 4) return VM_ERR_BAD_ARG;
   p.ws = (float*)workspace;
   p.drop_p = drop_p; p.seed = drop_seed;
+  if (drop_p > 0.f) alpha /= 1.0f - drop_p;                       // the kernel only masks; inverted-dropout scale folded here
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
   if (tn_skinny_bc(C) == 128) hipLaunchKernelGGL(tn_skinny_k<128>, dim3(p.c_pad / 128, p.splits, nseg), dim3(256), 0, (hipStream_t)stream, p);

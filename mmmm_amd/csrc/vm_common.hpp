@@ -117,6 +117,26 @@ __device__ __forceinline__ bool vm_keep(uint64_t seed, uint64_t idx, float p) {
   return vm_keep_bits(vm_hash4(seed, idx >> 2), (int)(idx & 3), vm_drop_threshold(p));
 }
 
+// Mask 8 consecutive bf16 elements (two hash words, 16 random bits per element) WITHOUT touching the kept values: dropped
+// elements become +0, kept ones keep their bits. The 1/(1-p) factor of inverted dropout is linear, so the fused consumers
+// (LoRA down-projection, factor-gradient kernels) apply it once to their fp32 accumulators instead of once per element —
+// one AND per element pair instead of convert / multiply / round / select per element, which made those HBM-streaming
+// kernels VALU-bound (+50 % on [6280 x 15360]). The result differs from dropout-then-matmul only by the bf16 rounding of
+// x/(1-p) that is no longer applied (it is the more accurate of the two).
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8m_t;
+__device__ __forceinline__ void vm_mask8(u16x8m_t& v, uint64_t h0, uint64_t h1, unsigned thr) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4m_t;
+  u32x4m_t w = __builtin_bit_cast(u32x4m_t, v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t h = j < 2 ? h0 : h1;
+    const unsigned lo = vm_keep_bits(h, (2 * j) & 3, thr) ? 0x0000FFFFu : 0u;
+    const unsigned hi = vm_keep_bits(h, (2 * j + 1) & 3, thr) ? 0xFFFF0000u : 0u;
+    w[j] &= lo | hi;
+  }
+  v = __builtin_bit_cast(u16x8m_t, w);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -550,7 +550,11 @@ def test_tn_skinny(dev, K, M, Cw):
     p, seed = 0.1, 99
     Wd = K.dropout(W, p, seed)
     d = K.tn_skinny(W, S, transpose_out=True, drop_p=p, drop_seed=seed, out_dtype=torch.float32)
-    assert rel_err(d, (Wd.float().T @ S.float()).T) < 1e-5
+    # the fused kernels mask the streamed operand and apply 1/(1-p) to the fp32 result (vm_mask8): exact against that form,
+    # and equal to dropout-then-contraction up to the bf16 rounding of x/(1-p) that the fused form does not perform
+    keep = (K.dropout(torch.ones_like(W), p, seed) != 0).float()
+    assert rel_err(d, ((W.float() * keep).T @ S.float()).T / (1 - p)) < 1e-5
+    assert rel_err(d, (Wd.float().T @ S.float()).T) < 4e-3
 
 
 def test_tn_skinny_segments(dev, K):
