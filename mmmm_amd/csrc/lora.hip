@@ -466,11 +466,15 @@ static int tn_skinny_splits(int M, int C) {
 
 extern "C" {
 
-// K-splits the kernel will use for (M, K): enough workgroups for two per CU, at least two K-tiles per split
+// K-splits the kernel will use for (M, K). Measured on MI355X (tools/bench_lora.py, kernel + reduce): about one workgroup
+// per CU is the optimum — [6280 x 15360] 45.3 us with 6 splits (594 workgroups), 38.8 us with 3 (297): every extra split
+// writes and re-reads M x 64 fp32 partials — and a short K (<= 16 K-tiles) is fastest in a single pass without the reduce
+// launch even when that leaves CUs idle ([6280 x 1792]: 11.0 us vs 12.8 us).
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
-  int want = (512 + m_tiles - 1) / m_tiles;
+  if (kt <= 16 && m_tiles >= 64) return 1;
+  int want = (256 + m_tiles - 1) / m_tiles;
   want = max(1, min(want, kt / 2));
   const int per = (kt + want - 1) / want;
   return (kt + per - 1) / per;
