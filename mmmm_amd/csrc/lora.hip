@@ -456,7 +456,7 @@ static int tn_skinny_splits(int M, int C) {
   const int bc = tn_skinny_bc(C);
   const int tiles = (C + bc - 1) / bc;
   const int steps = (M + 31) / 32;
-  int want = (384 + tiles - 1) / tiles;
+  int want = (512 + tiles - 1) / tiles;        // two workgroups per CU (32 KiB LDS each): measured optimum of a 192..768 sweep
   want = max(1, min(want, steps / 8));
   const int per = (steps + want - 1) / want;
   return (steps + per - 1) / per;
