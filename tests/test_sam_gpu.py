@@ -202,3 +202,40 @@ def test_training_step_end_to_end_matches_oracle(dev):
         g = dict(m.named_parameters())[name].grad
         assert g is not None, name
         assert rel(g.float(), sd[name].grad) < 8e-2, (name, rel(g.float(), sd[name].grad))
+
+
+def test_device_matching_equals_host_matching_for_every_target_count(dev):
+    """`vm_lsap_f32` route (no synchronisation) against the reference's route (SciPy on host copies) on one sample whose targets
+    have 0, 1, 3, 6 (= queries) and 9 (> queries) boxes: identical assignment, and the loss built from static-size device index
+    tensors equals the loss built from the host assignment — values, logged terms and gradients"""
+    from mmmm_amd.models.segvol.modeling.sam import InstanceSamLoss
+    il = InstanceSamLoss(use_neg_mask=False, box_l1_weight=5, box_giou_weight=2, disc_weight=2, disc_focal_gamma=2, disc_focal_alpha=0.85)
+    g = torch.Generator().manual_seed(3)
+    counts = [0, 1, 3, 6, 9]
+    nt, nq = len(counts), 6
+    offs, s = [], 0
+    for c in counts:
+        offs.append((s, s + c))
+        s += c
+    index_offsets = torch.tensor(offs, dtype=torch.int64)
+    centre = torch.rand(s, 3, generator=g) * 0.5 + 0.25
+    size = torch.rand(s, 3, generator=g) * 0.3 + 0.05
+    boxes_label = torch.cat([centre, size], 1).to(dev)
+    br = torch.cat([torch.rand(nt, 1 + nq, 3, generator=g) * 0.5 + 0.25, torch.rand(nt, 1 + nq, 3, generator=g) * 0.3 + 0.05], -1).to(dev)
+    dl = torch.randn(nt, nq, generator=g).to(dev)
+    dev_match = il._match_all(br, dl, boxes_label, index_offsets)
+    assert dev_match.is_cuda
+    costs, metas = il._match_costs(br[:, 1:], dl.float(), boxes_label, offs)
+    host_match = il._assign([c.cpu().numpy() for c in costs], metas, nt, nq)
+    assert torch.equal(dev_match.cpu(), host_match)
+    assert [(m >= 0).sum().item() for m in host_match] == [min(c, nq) for c in counts]
+    dummy = br.new_empty((nt, 1 + nq, 0, 0, 0))
+    res = []
+    for match in (dev_match, host_match):
+        b, d = br.clone().requires_grad_(), dl.clone().requires_grad_()
+        loss, log = il.compute_loss(dummy, dummy, b, d, None, boxes_label, index_offsets, match=match)
+        loss.backward()
+        res.append((loss.detach(), {k: v.detach() for k, v in log.items()}, b.grad, d.grad))
+    (l0, g0, b0, d0), (l1, g1, b1, d1) = res
+    assert torch.equal(l0, l1) and torch.equal(b0, b1) and torch.equal(d0, d1)
+    assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
