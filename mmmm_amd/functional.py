@@ -83,6 +83,21 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
 
 
 _WGRAD_STREAMS: dict = {}
+_HELD: list = []              # tensors kept referenced until the running backward pass ends (_hold_until_backward_ends)
+
+
+def _hold_until_backward_ends(t: torch.Tensor):
+    """Keep a second reference to `t` until autograd finishes the current backward pass.
+    The output gradient `dy` of a linear with a fused residual is handed back to autograd as the residual's gradient, and the
+    engine accumulates further gradients into such a buffer IN PLACE when it holds the last reference (input_buffer.cpp:
+    can_accumulate_inplace) — on the main stream, while the factor-gradient kernels forked to the side stream may still be
+    reading it. `record_stream` does not help (it only stops the allocator from recycling FREED memory). A second reference
+    makes the engine add out of place; once the backward pass is over nothing accumulates any more and the reference goes.
+    (Found by replaying a full-size step, tests/test_fullsize_gpu.py: the LoRA-B gradients of the decoder's dense / down_proj
+    linears came out different on every run.)"""
+    if not _HELD:
+        torch.autograd.Variable._execution_engine.queue_callback(_HELD.clear)
+    _HELD.append(t)
 WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
 
 
@@ -205,6 +220,8 @@ class _Linear(Function):
                           alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
         if ctx.has_residual and need[2]:
             g[2] = dy
+            if WGRAD_SIDE_STREAM and dy.is_cuda:
+                _hold_until_backward_ends(dy)
         # parameter gradients contract over token rows
         experts = ((0, W0, b0, A0, B0, 4), (1, W1, b1, A1, B1, 9)) if gated else ((0, W0, b0, A0, B0, 4),)
         tn_ok = x.dtype == torch.bfloat16 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
@@ -336,6 +353,8 @@ class _LayerNorm(Function):
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and b is not None and _norm_params_off_path(
                 (w, b), lambda dw_out, db_out: K.layernorm_bwd(x, w, dy, mean, rstd, need_dx=False, dw_out=dw_out, db_out=db_out)[1:],
                 (x, dy, mean, rstd)):
+            if ctx.has_res and dy.is_cuda and WGRAD_SIDE_STREAM:
+                _hold_until_backward_ends(dy)       # dy doubles as the residual's gradient while the side stream still reads it
             return K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=False)[0], None, None, None, (dy if ctx.has_res else None)
         dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=need_dw)
         return (dx, dw.to(w.dtype) if dw is not None else None, db.to(w.dtype) if db is not None else None, None,

@@ -1,0 +1,108 @@
+"""BASELINE configs[1] at FULL size (CogVLM-7B, 32 decoder + 63 ViT-E layers, SAM-B + iSAM unfrozen, LoRA r64 with dropout, bf16;
+batch 2 to keep the test short): the oracle cannot run this size, so parity is checked through size-independent properties:
+
+  * replay: the same step twice from the same state gives the same loss to 2e-6 (usually bit-identical; dropout masks are a pure function of
+    (seed, step, site, element); the only order-dependent sums of the forward are the fp32-atomic split-K products of the
+    hyper-network MLPs in the heads). Gradients: the backward contains order-dependent fp32 atomics
+    (ATen's trilinear-upsample / gather backward in the heads: 1e-7 relative), and a random-init network of this depth is
+    chaotic in backward — every attention layer with saturated random-init softmax amplifies the noise ~100x (measured with
+    tools/debug_replay.py: 0 at lm_head, 5e-7 at vg_proj, 6e-5 in the last decoder MLP, 2e-3 one attention layer further
+    down, 1e-2 .. 5e-2 through the ViT, where |grad| reaches 1e10). The tight comparison is therefore made upstream of the
+    first attention backward — lm_head, final norm, last decoder MLP, vg_proj, both grounding heads — and the other 1.7k
+    parameters are only required to agree loosely. (This replay is also what exposed a real race: the factor-gradient kernels
+    on the side stream read `dy` while autograd accumulated into it in place; see functional._off_critical_path.)
+  * recompute: activation checkpointing of every layer (the reference's mode) versus keeping every activation (the HBM-budgeted
+    mode of the benchmark) gives the same loss and the same gradients under the same comparison;
+  * permutation: swapping the two samples of the batch leaves the loss unchanged up to bf16 summation order."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def full(dev):
+    import bench
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    w = bench.WORKLOADS['phase-vg-448']
+    model, tok = bench.build(w, dev, 1.0)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    ddp = BucketedGradAllReduce(trainable, world_size=1)
+    batch = bench.make_batch(w, tok, 2, dev, seed=11)
+    yield model, ddp, batch
+    ddp.remove()
+    del model, ddp
+    torch.cuda.empty_cache()
+
+
+def run_step(model, ddp, batch, step_no: int, budget):
+    from mmmm_amd.models.lora import ActivationBudget, StepState
+    ActivationBudget.limit = budget
+    StepState.step = step_no          # training_step advances it: pin it so that two runs draw the same dropout masks
+    ddp.zero_grad()
+    loss = model.training_step(batch)
+    loss.backward()
+    ddp.finish()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.requires_grad}
+
+
+TIGHT = ('lm_head.', 'model.norm.', 'vg_proj.', 'sam.', 'isam_model.')
+NEAR = ('model.layers.31.mlp.',)           # one bf16 MLP below the final norm: still before the first attention backward
+
+
+def same_gradients(got, want):
+    for n, w in want.items():
+        nb = w.norm().item()
+        if nb < 1e-6:
+            continue            # analytically zero gradients (e.g. attention key biases): pure cancellation noise
+        if n.startswith(TIGHT):
+            assert ((got[n] - w).norm() / nb).item() < 1e-3, n
+        elif n.startswith(NEAR):
+            assert ((got[n] - w).norm() / nb).item() < 1e-2, n
+        else:       # chaotic region: same scale, nothing stronger can be asserted about a replay
+            assert 0.5 < got[n].norm().item() / nb < 2.0, n
+
+
+def same_loss(a, b):
+    """equal up to the order of the fp32 atomics of the small split-K products in the heads' forward (1e-7 relative)"""
+    return abs(a.item() - b.item()) <= 2e-6 * abs(b.item())
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_full_size_step_properties(dev, full):
+    model, ddp, batch = full
+    keep_all = 200 << 30
+    l0, g0 = run_step(model, ddp, batch, 7, keep_all)
+    assert torch.isfinite(l0) and all(torch.isfinite(g).all() for g in g0.values())
+    assert sum(1 for n in g0 if n.startswith(TIGHT)) >= 20 and all(g0[n].norm() > 0 for n in g0 if n.startswith('lm_head.'))
+    # replay
+    l1, g1 = run_step(model, ddp, batch, 7, keep_all)
+    assert same_loss(l0, l1)
+    same_gradients(g1, g0)
+    # a different step number draws different dropout masks
+    l2, _ = run_step(model, ddp, batch, 8, keep_all)
+    assert not same_loss(l0, l2) and abs(l2.item() - l0.item()) / abs(l0.item()) < 0.05
+    # recompute everything (reference mode) vs keep everything
+    l3, g3 = run_step(model, ddp, batch, 7, None)
+    assert same_loss(l0, l3)
+    same_gradients(g3, g0)
+    # sample permutation
+    perm = {k: ([v[1], v[0]] if isinstance(v, list) else v) for k, v in batch.items()}
+    perm['vlm_inputs'] = {k: v.flip(0) for k, v in batch['vlm_inputs'].items()}
+    # (dropout masks depend on the element index, so the two orders draw different masks: compare with dropout off)
+    cfgs = {id(m.lora_cfg): m.lora_cfg for m in model.modules() if getattr(m, 'lora_cfg', None) is not None}
+    saved = {k: c.lora_dropout for k, c in cfgs.items()}
+    for c in cfgs.values():
+        c.lora_dropout = 0.0
+    try:
+        a, _ = run_step(model, ddp, batch, 7, keep_all)
+        b, _ = run_step(model, ddp, perm, 7, keep_all)
+    finally:
+        for k, c in cfgs.items():
+            c.lora_dropout = saved[k]
+    assert abs(a.item() - b.item()) / abs(a.item()) < 2e-3, (a.item(), b.item())

@@ -1,0 +1,50 @@
+"""which parameter gradients differ between two replays of the same full-size step? (determinism check)"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+import bench
+from mmmm_amd.ddp import BucketedGradAllReduce
+from mmmm_amd.models.lora import ActivationBudget, StepState
+
+dev = torch.device('cuda:0')
+torch.cuda.set_device(dev)
+w = bench.WORKLOADS['phase-vg-448']
+model, tok = bench.build(w, dev, float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
+names = {id(p): n for n, p in model.named_parameters()}
+trainable = [p for p in model.parameters() if p.requires_grad]
+ddp = BucketedGradAllReduce(trainable, world_size=1)
+batch = bench.make_batch(w, tok, 2, dev, seed=11)
+ActivationBudget.limit = 200 << 30
+
+
+def run(limit=200 << 30):
+    ActivationBudget.limit = limit
+    StepState.step = 7
+    ddp.zero_grad()
+    loss = model.training_step(batch)
+    loss.backward()
+    ddp.finish()
+    torch.cuda.synchronize()
+    return loss.item(), {names[id(p)]: p.grad.detach().float().clone() for p in trainable}
+
+
+l0, g0 = run()
+l1, g1 = run()
+l2, g2 = run(None) if 'ckpt' in sys.argv else run()      # 'ckpt': third run recomputes every layer (reference mode)
+print('loss', l0, l1, l2)
+rows = []
+for n in g0:
+    d01 = (g0[n] - g1[n]).norm().item()
+    d12 = (g1[n] - g2[n]).norm().item()
+    nb = g0[n].norm().item()
+    rows.append((max(d01, d12) / max(nb, 1e-30), n, nb, d01, d12))
+rows.sort(reverse=True)
+print('params', len(rows), 'with any difference', sum(1 for r in rows if r[0] > 0))
+pat = sys.argv[2] if len(sys.argv) > 2 else ''
+for key in ('lm_head.weight', 'model.norm.weight', 'vg_proj.0.weight', 'vg_proj.2.weight', 'model.embed_tokens.weight', 'model.layers.31.mlp.language_mlp.down_proj.lora_B.default.weight', 'model.layers.31.input_layernorm.weight', 'sam.mask_decoder.output_hypernetworks_mlps.0.layers.0.weight', 'isam_model.mask_decoder.transformer.layers.0.mlp.lin1.weight', 'sam.image_encoder.blocks.11.mlp.linear2.weight', 'sam.image_encoder.blocks.0.attn.qkv.weight', 'model.vision.linear_proj.linear_proj.lora_B.default.weight', 'model.vision.transformer.layers.62.mlp.fc2.lora_B.default.weight'):
+    for r in rows:
+        if r[1] == key:
+            print(f'KEY {r[0]:.3e}  |g|={r[2]:.3e} d01={r[3]:.2e} d12={r[4]:.2e}  {r[1]}')
+for r in [r for r in rows if pat in r[1]][:40]:
+    print(f'{r[0]:.3e}  |g|={r[2]:.3e} d01={r[3]:.2e} d12={r[4]:.2e}  {r[1]}')
