@@ -9,7 +9,8 @@ from mmmm_amd.models.lora import ActivationBudget, StepState
 
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
-w = bench.WORKLOADS['phase-vg-448']
+import os
+w = bench.WORKLOADS[os.environ.get('VM_WORKLOAD', 'phase-vg-448')]
 model, tok = bench.build(w, dev, float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 names = {id(p): n for n, p in model.named_parameters()}
 trainable = [p for p in model.parameters() if p.requires_grad]
@@ -48,3 +49,23 @@ for key in ('lm_head.weight', 'model.norm.weight', 'vg_proj.0.weight', 'vg_proj.
             print(f'KEY {r[0]:.3e}  |g|={r[2]:.3e} d01={r[3]:.2e} d12={r[4]:.2e}  {r[1]}')
 for r in [r for r in rows if pat in r[1]][:40]:
     print(f'{r[0]:.3e}  |g|={r[2]:.3e} d01={r[3]:.2e} d12={r[4]:.2e}  {r[1]}')
+
+# anomaly scan: a parameter whose replay noise is far above that of its neighbours (same block) points at a race rather than
+# at conditioning (the signature of the dy race: lora_B of dense / down_proj at O(1) while the rest of the layer sat at 1e-3)
+import re, statistics
+groups = {}
+for r in rows:
+    if r[2] < 1e-6:
+        continue
+    m = re.match(r'(.*?(?:layers|blocks)\.\d+)\.', r[1])
+    groups.setdefault(m.group(1) if m else r[1].split('.')[0], []).append(r)
+flagged = 0
+for g, rs in groups.items():
+    if len(rs) < 4:
+        continue
+    med = statistics.median(r[0] for r in rs)
+    for r in rs:
+        if r[0] > 20 * max(med, 1e-7):
+            flagged += 1
+            print(f'ANOMALY {r[1]}: {r[0]:.2e} vs block median {med:.2e}')
+print('anomalies:', flagged)
