@@ -20,18 +20,32 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def full(dev):
+def _build(dev, workload):
     import bench
     from mmmm_amd.ddp import BucketedGradAllReduce
-    w = bench.WORKLOADS['phase-vg-448']
+    w = bench.WORKLOADS[workload]
     model, tok = bench.build(w, dev, 1.0)
     trainable = [p for p in model.parameters() if p.requires_grad]
     ddp = BucketedGradAllReduce(trainable, world_size=1)
     batch = bench.make_batch(w, tok, 2, dev, seed=11)
+    return model, ddp, batch
+
+
+@pytest.fixture
+def full(dev):
+    model, ddp, batch = _build(dev, 'phase-vg-448')
     yield model, ddp, batch
     ddp.remove()
-    del model, ddp
+    del model, ddp, batch
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture
+def full_vlm(dev):
+    model, ddp, batch = _build(dev, 'phase-vlm-448')
+    yield model, ddp, batch
+    ddp.remove()
+    del model, ddp, batch
     torch.cuda.empty_cache()
 
 
@@ -106,3 +120,34 @@ def test_full_size_step_properties(dev, full):
         for k, c in cfgs.items():
             c.lora_dropout = saved[k]
     assert abs(a.item() - b.item()) / abs(a.item()) < 2e-3, (a.item(), b.item())
+
+
+def test_full_size_backward_is_bit_reproducible_without_the_heads(dev, full_vlm):
+    """phase-vlm (no grounding heads, hence none of their atomics) at full size: the backward of the 7B decoder + ViT-E is
+    bit-reproducible, so three things that must not change results can be checked to the last bit on 1.4k parameter gradients —
+    a replay, every weight-gradient kernel moved from the side stream to the main stream, and every layer recomputed instead of
+    kept. Only the norm weights / biases (their column sums use fp32 atomics: 1e-5 .. 1e-4 after bf16 rounding) and the patch
+    embedding (ATen's atomic conv-weight / interpolate backward) may differ."""
+    import mmmm_amd.functional as Fh
+    model, ddp, batch = full_vlm
+    keep_all = 200 << 30
+    l0, g0 = run_step(model, ddp, batch, 3, keep_all)
+
+    def check(l, g, what):
+        assert torch.equal(l, l0), what
+        diff = [n for n in g0 if not torch.equal(g[n], g0[n])]
+        atomics = ('norm', 'patch_embedding.')      # norm column sums (ours, fp32 atomics); ATen conv / interpolate backward of the patch embedding
+        assert all(any(a in n for a in atomics) for n in diff), (what, [n for n in diff if not any(a in n for a in atomics)][:5])
+        for n in diff:
+            assert rel(g[n], g0[n]) < 2e-3, (what, n)
+        return len(diff)
+
+    check(*run_step(model, ddp, batch, 3, keep_all), 'replay')
+    assert Fh.WGRAD_SIDE_STREAM
+    Fh.WGRAD_SIDE_STREAM = False
+    try:
+        check(*run_step(model, ddp, batch, 3, keep_all), 'weight gradients on the main stream')
+    finally:
+        Fh.WGRAD_SIDE_STREAM = True
+    check(*run_step(model, ddp, batch, 3, None), 'every layer recomputed')
+    assert len(g0) > 1400

@@ -32,6 +32,10 @@ def run(limit=200 << 30):
 
 l0, g0 = run()
 l1, g1 = run()
+if 'nosidestream' in sys.argv:          # third run with every weight-gradient kernel on the main stream
+    import mmmm_amd.functional as Fh
+    Fh.WGRAD_SIDE_STREAM = False
+    model.concurrent_heads = False
 l2, g2 = run(None) if 'ckpt' in sys.argv else run()      # 'ckpt': third run recomputes every layer (reference mode)
 print('loss', l0, l1, l2)
 rows = []
