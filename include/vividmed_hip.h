@@ -320,6 +320,19 @@ typedef struct vm_attn_args {
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
 
+/* Fused Dice + sigmoid-focal loss of full-resolution mask logits: DiceFocalLoss.dice / .focal, mmmm/models/loss.py:32-56
+ * (focal = luolib.losses.sigmoid_focal_loss [external]: the torchvision formula, reduction none).
+ * x fp32 [rows, n] logits (rows = prompts x channels, n = D*H*W), target [rows, n] bytes (non-zero = foreground) or NULL
+ * (no target: dice = 1, focal against zeros). alpha < 0 = no alpha weighting.
+ * fwd: sums[row] = (sum t*p, sum p, sum t, sum focal), out[row] = (dice = 1 - 2 sum(t p) / max(sum t + sum p, 1e-8), sum focal);
+ *      one streaming pass + a fixed-order second stage (deterministic); workspace from vm_dice_focal_workspace.
+ * bwd: dx[row, i] = g_dice[row] * d dice_row / dx_i + g_focal[row] * d focal_i / dx_i (g_* may be NULL = 0). */
+int vm_dice_focal_workspace(int rows, int64_t n, int64_t* bytes_host);
+int vm_dice_focal_fwd(const float* x, const unsigned char* target, int rows, int64_t n, float gamma, float alpha, float* sums,
+                      float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int vm_dice_focal_bwd(const float* x, const unsigned char* target, int rows, int64_t n, float gamma, float alpha, const float* sums,
+                      const float* g_dice, const float* g_focal, float* dx, void* stream);
+
 /* Rectangular linear sum assignment (Hungarian matching) of many small cost matrices on the device:
  * InstanceSamLoss._match_instances, segvol/modeling/sam.py:243 (`scipy.optimize.linear_sum_assignment` on the host in the
  * reference: one device->host synchronisation per target). cost[p * ld_prob + r * ld_row + c], fp32, solved in double by the

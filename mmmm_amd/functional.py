@@ -592,6 +592,32 @@ def overwrite_rows_(base, src, idx):
     return _OverwriteRows.apply(base, src, idx)
 
 
+# ----------------------------------------------------------------------------- Dice + focal loss of mask logits
+class _DiceFocal(Function):
+    """per-row Dice loss and per-row SUM of the sigmoid-focal loss of fp32 mask logits (mmmm/models/loss.py:32-56) in one
+    streaming pass each way instead of ~40 element-wise / reduction launches"""
+    @staticmethod
+    def forward(ctx, x, target, gamma, alpha):
+        sums, out = K.dice_focal_fwd(x, target, gamma, alpha)
+        ctx.save_for_backward(x, target, sums)
+        ctx.cfg = (gamma, alpha)
+        return out[:, 0], out[:, 1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_dice, g_focal):
+        x, target, sums = ctx.saved_tensors
+        gamma, alpha = ctx.cfg
+        gd = g_dice.float().contiguous() if g_dice is not None else None
+        gf = g_focal.float().contiguous() if g_focal is not None else None
+        return K.dice_focal_bwd(x, target, gamma, alpha, sums, gd, gf), None, None, None
+
+
+def dice_focal(x, target, gamma: float, alpha: float | None):
+    """x fp32 [R, n] logits, target uint8 [R, n] | None -> (dice [R], focal_sum [R])"""
+    return _DiceFocal.apply(x, target, gamma, alpha)
+
+
 # ----------------------------------------------------------------------------- weighted CE over the vocabulary
 class _WeightedCE(Function):
     """loss = sum_r ce_r * w_r / n_valid  (modeling_cogvlm.py:610-627); also returns the per-row CE (no grad)."""

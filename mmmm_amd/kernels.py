@@ -465,6 +465,29 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *
              dtype_code(p.dtype), stream())
 
 
+# ------------------------------------------------------------------ Dice + focal loss
+def dice_focal_fwd(x: torch.Tensor, target: torch.Tensor | None, gamma: float, alpha: float | None):
+    """x fp32 [R, n], target uint8 [R, n] | None -> (sums [R, 4], out [R, 2] = (dice, focal sum)); mmmm/models/loss.py:32-56"""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    assert target is None or (target.dtype == torch.uint8 and target.shape == x.shape and target.is_contiguous())
+    R, n = x.shape
+    sums = torch.empty(R, 4, dtype=torch.float32, device=x.device)
+    out = torch.empty(R, 2, dtype=torch.float32, device=x.device)
+    nb = C.c_int64(0)
+    hip.call('vm_dice_focal_workspace', R, n, C.addressof(nb))
+    ws = torch.empty(max(nb.value // 4, 1), dtype=torch.float32, device=x.device)
+    hip.call('vm_dice_focal_fwd', ptr(x), ptr(target), R, n, float(gamma), -1.0 if alpha is None else float(alpha), ptr(sums), ptr(out),
+             ptr(ws), nb.value, stream())
+    return sums, out
+
+
+def dice_focal_bwd(x, target, gamma: float, alpha: float | None, sums, g_dice, g_focal):
+    dx = torch.empty_like(x)
+    hip.call('vm_dice_focal_bwd', ptr(x), ptr(target), x.shape[0], x.shape[1], float(gamma), -1.0 if alpha is None else float(alpha),
+             ptr(sums), ptr(g_dice), ptr(g_focal), ptr(dx), stream())
+    return dx
+
+
 # ------------------------------------------------------------------ Hungarian matching
 LSAP_MAX_COLS = 64
 

@@ -1,5 +1,7 @@
 """DiceFocalLoss of the reference (mmmm/models/loss.py) — same constructor and return keys.
-The reductions run over full-resolution fp32 mask volumes (HBM-bound); see DESIGN.md for the kernel plan."""
+On the GPU (fp32 logits, boolean targets — what the training step passes) both terms come from the fused kernels
+`vm_dice_focal_fwd / _bwd` (one streaming pass each way); the element-wise torch form below is the CPU / generic-dtype path
+and what the fused kernels are tested against."""
 from __future__ import annotations
 
 import torch
@@ -49,11 +51,26 @@ class DiceFocalLoss(nn.Module):
         assert input.ndim == 5
         if target is not None:
             assert input.shape == target.shape
-        dice, focal = self.dice(input, target), self.focal(input, target)
-        if reduce_batch:
-            dice, focal = dice.mean(), focal.mean()
+        if input.is_cuda and input.dtype == torch.float32 and (target is None or target.dtype in (torch.bool, torch.uint8)):
+            # fused HIP path (vm_dice_focal_*): per-(prompt, channel) Dice and focal sums in one pass over the logits
+            from .. import functional as Fh
+            P, Cn = input.shape[:2]
+            n = input[0, 0].numel()
+            t = None if target is None else target.reshape(P * Cn, n).contiguous().view(torch.uint8)
+            plain_ce = self.focal_gamma < _EPS                  # reference :51-52: plain BCE, no alpha
+            d, fsum = Fh.dice_focal(input.reshape(P * Cn, n).contiguous(), t, 0.0 if plain_ce else self.focal_gamma,
+                                    None if plain_ce else self.focal_alpha)
+            d, fsum = d.view(P, Cn), fsum.view(P, Cn)
+            if reduce_batch:
+                dice, focal = d.mean(), fsum.sum() / (P * Cn * n)
+            else:
+                dice, focal = d.mean(1), fsum.sum(1) / (Cn * n)
         else:
-            dice, focal = dice.flatten(1).mean(1), focal.flatten(1).mean(1)
+            dice, focal = self.dice(input, target), self.focal(input, target)
+            if reduce_batch:
+                dice, focal = dice.mean(), focal.mean()
+            else:
+                dice, focal = dice.flatten(1).mean(1), focal.flatten(1).mean(1)
         total = self.dice_weight * dice + self.focal_weight * focal
         if return_dict:
             key = 'ce' if self.focal_gamma < _EPS else f'focal-{self.focal_gamma:.1f}'

@@ -664,3 +664,34 @@ def test_lsap_matches_scipy(dev, K):
         row, col = linear_sum_assignment(c)
         assert row.tolist() == list(range(nr))
         assert got[i, :nr].tolist() == col.tolist(), (i, c, col, got[i])
+
+
+@pytest.mark.parametrize('gamma,alpha', [(2.0, None), (2.0, 0.85), (1.5, 0.25), (0.0, None)])
+def test_dice_focal_fused_matches_torch_form(dev, K, gamma, alpha):
+    """vm_dice_focal_fwd / _bwd against the element-wise torch form of the same module (itself pinned to the reference by
+    fixture F7): values and input gradients, reduce_batch on / off, missing target, an all-background row (clipped Dice
+    denominator is not reachable with sigmoid > 0, but sum t = 0 is), sizes that are not a multiple of the chunk"""
+    from mmmm_amd.models.loss import DiceFocalLoss
+    g = torch.Generator().manual_seed(int(gamma * 10) + (0 if alpha is None else 7))
+    m = DiceFocalLoss(dice_weight=2, focal_weight=3, focal_gamma=gamma, focal_alpha=alpha)
+    for shape in [(3, 1, 4, 37, 53), (2, 2, 1, 300, 301), (1, 1, 1, 8, 8)]:
+        x = (torch.randn(shape, generator=g) * 3).to(dev)
+        t = (torch.rand(shape, generator=g) < 0.2).to(dev)
+        t[0, 0] = False                                            # all-background row
+        for target in (t, None):
+            for reduce_batch in (True, False):
+                xa = x.clone().requires_grad_()
+                xb = x.double().clone().requires_grad_()
+                got = m(xa, target, reduce_batch=reduce_batch, return_dict=True)
+                # reference form in fp64 on the same device: the generic path of the same module (non-fp32 input)
+                want = m(xb, target, reduce_batch=reduce_batch, return_dict=True)
+                assert got.keys() == want.keys()
+                for k in got:
+                    assert got[k].shape == want[k].shape and rel_err(got[k], want[k]) < 2e-5, (k, shape, reduce_batch)
+                w = torch.randn(got['total'].shape, generator=g).to(dev) if not reduce_batch else None
+                (got['total'] * w).sum().backward() if w is not None else got['total'].backward()
+                (want['total'] * w.double()).sum().backward() if w is not None else want['total'].backward()
+                assert rel_err(xa.grad, xb.grad) < 2e-5, (shape, reduce_batch, target is None)
+    # deterministic: fixed-order second stage
+    a = m(x, t, return_dict=True)['total']
+    assert torch.equal(a, m(x, t, return_dict=True)['total'])
