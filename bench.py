@@ -297,6 +297,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    model.freeze_python_gc()          # model, buckets, optimizer state and the batch are permanent: keep the cyclic GC off them
     ms0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):

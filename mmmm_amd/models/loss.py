@@ -4,6 +4,8 @@ On the GPU (fp32 logits, boolean targets — what the training step passes) both
 and what the fused kernels are tested against."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -24,6 +26,8 @@ def sigmoid_focal_loss(x: torch.Tensor, y: torch.Tensor, gamma: float, alpha: fl
 
 
 class DiceFocalLoss(nn.Module):
+    fused = os.environ.get('VM_DICE_FUSED', '1') == '1'        # 0: element-wise torch form on the GPU as well (A/B measurements)
+
     def __init__(self, dice_weight: float, focal_weight: float, focal_gamma: float, focal_alpha: float | None = None):
         super().__init__()
         assert focal_gamma >= 0
@@ -51,7 +55,7 @@ class DiceFocalLoss(nn.Module):
         assert input.ndim == 5
         if target is not None:
             assert input.shape == target.shape
-        if input.is_cuda and input.dtype == torch.float32 and (target is None or target.dtype in (torch.bool, torch.uint8)):
+        if self.fused and input.is_cuda and input.dtype == torch.float32 and (target is None or target.dtype in (torch.bool, torch.uint8)):
             # fused HIP path (vm_dice_focal_*): per-(prompt, channel) Dice and focal sums in one pass over the logits
             from .. import functional as Fh
             P, Cn = input.shape[:2]
