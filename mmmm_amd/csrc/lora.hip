@@ -466,15 +466,16 @@ static int tn_skinny_splits(int M, int C) {
 
 extern "C" {
 
-// K-splits the kernel will use for (M, K). Measured on MI355X (tools/bench_lora.py, kernel + reduce): about one workgroup
-// per CU is the optimum — [6280 x 15360] 45.3 us with 6 splits (594 workgroups), 38.8 us with 3 (297): every extra split
-// writes and re-reads M x 64 fp32 partials — and a short K (<= 16 K-tiles) is fastest in a single pass without the reduce
-// launch even when that leaves CUs idle ([6280 x 1792]: 11.0 us vs 12.8 us).
+// K-splits the kernel will use for (M, K). Measured on MI355X: in isolation (tools/bench_lora.py, kernel + reduce) about one
+// workgroup per CU is the optimum — [6280 x 15360] 45.3 us with 6 splits (594 workgroups), 38.8 us with 3 (297): every extra
+// split writes and re-reads M x 64 fp32 partials — but inside the training step, where the side stream's kernels compete for
+// the CUs, 1.5 workgroups per CU is better (step time 376.6 ms vs 378.6 ms at one per CU, 377.4 ms at two). A short K
+// (<= 16 K-tiles) is fastest in a single pass without the reduce launch ([6280 x 1792]: 11.0 us vs 12.8 us).
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
   if (kt <= 16 && m_tiles >= 64) return 1;
-  int want = (256 + m_tiles - 1) / m_tiles;
+  int want = (384 + m_tiles - 1) / m_tiles;
   want = max(1, min(want, kt / 2));
   const int per = (kt + want - 1) / want;
   return (kt + per - 1) / per;
