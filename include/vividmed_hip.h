@@ -320,6 +320,13 @@ typedef struct vm_attn_args {
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
 
+/* Trilinear up-sampling of fp32 volumes, F.interpolate(x, size, mode='trilinear', align_corners=False) as used on the mask
+ * logits in Sam._predict_masks (segvol/modeling/sam.py:57-87). x [n, di, hi, wi] -> y [n, dout, ho, wo] (n = prompts x channels).
+ * bwd: gx [n, di, hi, wi] from gy [n, dout, ho, wo] by GATHERING (one thread per input voxel, fixed order): deterministic,
+ * unlike the atomic scatter of ATen's backward. */
+int vm_upsample_trilinear3d_fwd(const float* x, float* y, int n, int di, int hi, int wi, int dout, int ho, int wo, void* stream);
+int vm_upsample_trilinear3d_bwd(const float* gy, float* gx, int n, int di, int hi, int wi, int dout, int ho, int wo, void* stream);
+
 /* Fused Dice + sigmoid-focal loss of full-resolution mask logits: DiceFocalLoss.dice / .focal, mmmm/models/loss.py:32-56
  * (focal = luolib.losses.sigmoid_focal_loss [external]: the torchvision formula, reduction none).
  * x fp32 [rows, n] logits (rows = prompts x channels, n = D*H*W), target [rows, n] bytes (non-zero = foreground) or NULL

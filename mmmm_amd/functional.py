@@ -592,6 +592,36 @@ def overwrite_rows_(base, src, idx):
     return _OverwriteRows.apply(base, src, idx)
 
 
+# ----------------------------------------------------------------------------- trilinear up-sampling of mask logits
+UPSAMPLE_HIP = os.environ.get('VM_UPSAMPLE_HIP', '1') == '1'      # 0: ATen's interpolate on the GPU as well (A/B measurements)
+
+
+class _UpsampleTrilinear(Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_shape = tuple(x.shape[1:])
+        return K.upsample_trilinear3d(x, size)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return K.upsample_trilinear3d_bwd(gy.contiguous(), ctx.in_shape), None
+
+
+def upsample_trilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(x, size, mode='trilinear') for [..., d, h, w] volumes (segvol/modeling/sam.py:57-87). fp32 device tensors
+    go through the HIP kernels (gather-form, deterministic backward); anything else through ATen."""
+    size = tuple(int(v) for v in size)
+    if UPSAMPLE_HIP and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 4 and x.numel() > 0:
+        lead = x.shape[:-3]
+        y = _UpsampleTrilinear.apply(x.reshape(-1, *x.shape[-3:]).contiguous(), size)
+        return y.view(*lead, *size)
+    import torch.nn.functional as F
+    x5 = x.reshape(1, -1, *x.shape[-3:]) if x.dim() != 5 else x
+    y = F.interpolate(x5, size, mode='trilinear')
+    return y.view(*x.shape[:-3], *size)
+
+
 # ----------------------------------------------------------------------------- Dice + focal loss of mask logits
 class _DiceFocal(Function):
     """per-row Dice loss and per-row SUM of the sigmoid-focal loss of fp32 mask logits (mmmm/models/loss.py:32-56) in one

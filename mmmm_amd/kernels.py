@@ -465,6 +465,26 @@ def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *
              dtype_code(p.dtype), stream())
 
 
+# ------------------------------------------------------------------ trilinear up-sampling
+def upsample_trilinear3d(x: torch.Tensor, size) -> torch.Tensor:
+    """x fp32 [n, d, h, w] -> [n, *size]: F.interpolate(mode='trilinear', align_corners=False)"""
+    assert x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    n, d, h, w = x.shape
+    D, H, W = (int(v) for v in size)
+    y = torch.empty(n, D, H, W, dtype=x.dtype, device=x.device)
+    hip.call('vm_upsample_trilinear3d_fwd', ptr(x), ptr(y), n, d, h, w, D, H, W, stream())
+    return y
+
+
+def upsample_trilinear3d_bwd(gy: torch.Tensor, in_shape) -> torch.Tensor:
+    assert gy.dtype == torch.float32 and gy.dim() == 4 and gy.is_contiguous()
+    n, D, H, W = gy.shape
+    d, h, w = (int(v) for v in in_shape)
+    gx = torch.empty(n, d, h, w, dtype=gy.dtype, device=gy.device)
+    hip.call('vm_upsample_trilinear3d_bwd', ptr(gy), ptr(gx), n, d, h, w, D, H, W, stream())
+    return gx
+
+
 # ------------------------------------------------------------------ Dice + focal loss
 def dice_focal_fwd(x: torch.Tensor, target: torch.Tensor | None, gamma: float, alpha: float | None):
     """x fp32 [R, n], target uint8 [R, n] | None -> (sums [R, 4], out [R, 2] = (dice, focal sum)); mmmm/models/loss.py:32-56"""

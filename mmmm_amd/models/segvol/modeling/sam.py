@@ -76,7 +76,7 @@ class Sam(nn.Module):
         outs = []
         for i in range(len(image)):
             low = lows[i][:, 0]
-            outs.append(F.interpolate(low[None], image[i].shape[1:], mode='trilinear')[0] if low.shape[0] > 0 else low)
+            outs.append(Fh.upsample_trilinear(low, image[i].shape[1:]) if low.shape[0] > 0 else low)
         return outs
 
 
@@ -105,7 +105,7 @@ class InstanceSam(Sam):
             x = self.box_head[4](Fh.relu(self.box_head[2](Fh.relu(self.box_head[0](emb)))))
             boxes.append(x.float().sigmoid())
             discs.append(self.disc_head[2](Fh.relu(self.disc_head[0](emb[:, 1:].contiguous())))[..., 0])
-        masks = [F.interpolate(m, image[i].shape[1:], mode='trilinear') if m is not None else None for i, m in enumerate(lows)]
+        masks = [Fh.upsample_trilinear(m, image[i].shape[1:]) if m is not None else None for i, m in enumerate(lows)]
         return InstanceSamOutput(masks, lows, boxes, discs)
 
 

@@ -695,3 +695,28 @@ def test_dice_focal_fused_matches_torch_form(dev, K, gamma, alpha):
     # deterministic: fixed-order second stage
     a = m(x, t, return_dict=True)['total']
     assert torch.equal(a, m(x, t, return_dict=True)['total'])
+
+
+@pytest.mark.parametrize('inp,out', [((1, 28, 28), (1, 112, 112)), ((1, 112, 112), (1, 448, 448)), ((8, 16, 16), (32, 64, 64)),
+                                     ((2, 7, 9), (5, 30, 20)), ((4, 12, 12), (4, 12, 12)), ((3, 10, 10), (2, 5, 7))])
+def test_upsample_trilinear_matches_aten(dev, K, inp, out):
+    """vm_upsample_trilinear3d_fwd / _bwd == F.interpolate(mode='trilinear', align_corners=False) and its autograd, for 2D (depth 1)
+    and 3D volumes, non-integer ratios, identity and down-sampling; the gather-form backward is bit-reproducible"""
+    import torch.nn.functional as F
+    from mmmm_amd import functional as Fh
+    g = torch.Generator().manual_seed(sum(inp) + sum(out))
+    x = torch.randn(3, *inp, generator=g).to(dev)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y = Fh.upsample_trilinear(xa, out)
+    ref = F.interpolate(xb[None], out, mode='trilinear')[0]
+    assert y.shape == ref.shape and rel_err(y, ref) < 1e-6
+    w = torch.randn(y.shape, generator=g).to(dev)
+    (y * w).sum().backward()
+    (ref * w).sum().backward()
+    assert rel_err(xa.grad, xb.grad) < 1e-5
+    xc = x.clone().requires_grad_()
+    (Fh.upsample_trilinear(xc, out) * w).sum().backward()
+    assert torch.equal(xc.grad, xa.grad)
+    # 5-D form [P, M, d, h, w] as the instance head uses it
+    x5 = torch.randn(2, 3, *inp, generator=g).to(dev)
+    assert rel_err(Fh.upsample_trilinear(x5, out), F.interpolate(x5, out, mode='trilinear')) < 1e-6
