@@ -301,11 +301,18 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         self._lora_transposes.refresh()          # one launch: K-contiguous LoRA factors for this step's backward
         vlm_inputs = batch['vlm_inputs']
         input_ids = vlm_inputs['input_ids']
-        # small integer tensors the host will need after the forward has been enqueued: copy them out NOW
-        ids_host = _HostCopy(input_ids[:, 1:]) if self.sam is not None else None
+        # Small integer tensors the host needs after the forward has been enqueued (token ids to locate </p>, box index
+        # offsets). The batch is born on the host (collate); when it still carries those copies (`batch['host']`, see
+        # data/synthetic.py) nothing is transferred. Otherwise they are copied out NOW; the copy queues behind everything already
+        # on the stream, so reading it later makes the host wait until the GPU has finished the previous step (measured harmless
+        # for the step time, 368.1 vs 367.9 ms: the step is GPU-bound and the host re-builds its lead during the forward).
+        host = batch.get('host') or {}
+        ids_src = host['input_ids'] if host.get('input_ids') is not None else input_ids
+        ids_host = _HostCopy(ids_src[:, 1:]) if self.sam is not None else None
         offs_host = None
-        if self.sam is not None and batch.get('index_offsets') is not None:
-            offs_host = [None if o is None else _HostCopy(o) for o in batch['index_offsets']]
+        offs_src = host.get('index_offsets') if host.get('index_offsets') is not None else batch.get('index_offsets')
+        if self.sam is not None and offs_src is not None:
+            offs_host = [None if o is None else _HostCopy(o) for o in offs_src]
         out: CausalLMOutputWithPast = self(**vlm_inputs, image=batch['image'], patch_size=batch['patch_size'],
                                            pool_size=batch['pool_size'], return_dict=True, output_hidden_states=True)
         if self.sam is None:
