@@ -15,7 +15,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         if r["Counter_Name"] != c: continue
-        m = re.search(r"(gemm256_k<\w+>|gemm_nt_k<\d, \w+>)", r["Kernel_Name"])
+        m = re.search(r"(gemm256_k<[\w, ]+>|gemm_nt_k<[\w, ]+>)", r["Kernel_Name"])
         if not m: continue
         a = agg[m.group(1)]; a[0] += 1; a[1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": n, "sum": v} for k, (n, v) in agg.items()}
