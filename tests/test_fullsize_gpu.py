@@ -108,6 +108,7 @@ def test_full_size_step_properties(dev, full):
     # sample permutation
     perm = {k: ([v[1], v[0]] if isinstance(v, list) else v) for k, v in batch.items()}
     perm['vlm_inputs'] = {k: v.flip(0) for k, v in batch['vlm_inputs'].items()}
+    perm['host'] = dict(input_ids=batch['host']['input_ids'].flip(0), index_offsets=batch['host']['index_offsets'][::-1])
     # (dropout masks depend on the element index, so the two orders draw different masks: compare with dropout off)
     cfgs = {id(m.lora_cfg): m.lora_cfg for m in model.modules() if getattr(m, 'lora_cfg', None) is not None}
     saved = {k: c.lora_dropout for k, c in cfgs.items()}
