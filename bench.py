@@ -161,7 +161,16 @@ def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
     L = 1 + (Np + 2) + 1 + workload['text']
     h, i, d, f = cfg.hidden_size, cfg.intermediate_size, vc['hidden_size'], vc['intermediate_size']
     g = torch.Generator().manual_seed(0)
-    r = lambda *s: torch.randn(*s, generator=g) * 0.02
+    base = torch.randn(1 << 20, generator=g) * 0.02
+
+    _by_shape: dict = {}
+
+    def r(*s):       # timing only: a tiled 1M-element normal sample, one buffer per distinct shape (0.6 G normals through the
+        if s in _by_shape:       # scalar generator took 20 s of this leg, first-touch page faults of 2.4 GB another 16 s)
+            return _by_shape[s]
+        n = math.prod(s)
+        t = _by_shape[s] = base.repeat(-(-n // base.numel()))[:n].view(*s)
+        return t
     sd = {}
     pre = 'model.layers.0'
     for e in ('vision', 'language'):
@@ -185,21 +194,41 @@ def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
     cos, sin = O.rope_tables(h // cfg.num_attention_heads, L, torch.float32)
 
     def t_lm():
-        x = r(1, L, h).requires_grad_()
+        x = r(1, L, h).clone().requires_grad_()
         y = O.decoder_layer(sd, ocfg, pre, x, tt, pos, am, cos, sin)
         y.sum().backward()
 
     def t_vit():
-        x = r(Nv, d).requires_grad_()
+        x = r(Nv, d).clone().requires_grad_()
         O.vit_layer(sd, ocfg, vp, x, [Nv]).sum().backward()
 
     def t_head():
-        x = r(L, h).requires_grad_()
+        x = r(L, h).clone().requires_grad_()
         lg = torch.nn.functional.linear(x, sd['lm_head.weight']).float()
         O.weighted_ce(lg, torch.randint(0, cfg.vocab_size, (L,), generator=g), torch.ones(L)).backward()
 
+    def t_small():          # the same three pieces on a 32-token problem: pages in the BLAS / autograd paths, costs milliseconds
+        xs = r(1, 32, h).clone().requires_grad_()
+        O.decoder_layer(sd, ocfg, pre, xs, tt[:, :32], pos[:, :32], am[:, :32], cos, sin).sum().backward()
+        xv = r(33, d).clone().requires_grad_()
+        O.vit_layer(sd, ocfg, vp, xv, [33]).sum().backward()
+
+    # thread count: all host cores is not the fastest choice for layer-sized GEMMs on a many-core box (round 1 measured 27 s per
+    # layer with 256 threads, vs 4.7 s on the 8 cores of the development container) — probe a few counts on the small problem
+    # and use the fastest; `cores` reports the count actually used
+    best, best_t = cores, None
+    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+        torch.set_num_threads(n)
+        t_small()
+        t0 = time.perf_counter()
+        t_small()
+        dt_ = time.perf_counter() - t0
+        if best_t is None or dt_ < best_t:
+            best, best_t = n, dt_
+    torch.set_num_threads(best)
+    cores = best
+
     def clock(fn):
-        fn()  # warm
         t0 = time.perf_counter()
         fn()
         return time.perf_counter() - t0
@@ -208,15 +237,86 @@ def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
     per_image = cfg.num_hidden_layers * a + vc['num_hidden_layers'] * b + c
     return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': (f'oracle fp32 fwd+bwd of 1 true-width decoder layer (L={L}) {a:.2f}s, 1 true-width ViT layer (Nv={Nv}) {b:.2f}s, '
-                       f'lm_head+CE {c:.2f}s on 1 image; extrapolated x{cfg.num_hidden_layers}/x{vc["num_hidden_layers"]} layers '
-                       f'(grounding heads not included)')}
+                       f'lm_head+CE {c:.2f}s on 1 image, one run each after a small-shape warm-up, {cores} of {os.cpu_count()} host threads '
+                       f'(fastest of a probe); extrapolated x{cfg.num_hidden_layers}/x{vc["num_hidden_layers"]} layers (grounding heads not included)')}
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    <same arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1) and return its exit code. Rank 0 of the child
+    job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run_cpu(args, rank: int, world: int):
+    """the N-rank plumbing of this file (rendezvous, bucketed all-reduce overlapped with backward, barrier + max-over-ranks
+    timing, one JSON line from rank 0) on CPU tensors over gloo. The VividMed model itself has no CPU path: a toy network
+    stands in, and the line says so."""
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29512')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(), torch.nn.Linear(256, 8))
+    ddp = BucketedGradAllReduce(net.parameters(), world_size=world, bucket_bytes=64 << 10)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    batches = [torch.randn(args.batch, 64, generator=torch.Generator().manual_seed(1000 * rank + i)) for i in range(max(1, args.batches))]
+
+    def step(i):
+        ddp.zero_grad()
+        loss = net(batches[i % len(batches)]).square().mean()
+        loss.backward()
+        ddp.finish()
+        ddp.clip_grad_norm_(1.0)
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        # every rank must hold the same parameters after identical updates of averaged gradients
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        ref = flat.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(flat, ref), 'ranks diverged'
+    if rank == 0:
+        print(json.dumps({'metric': 'train images/sec/node', 'value': world * args.batch * args.steps / dt, 'unit': 'images/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                          'data': 'dry-run (CPU, toy network): launcher / collective plumbing check, NOT a measurement',
+                          'dry_run': True, 'config': {'workload': 'dry-run-cpu', 'parallelism': f'dp{world}', 'backend': 'gloo'},
+                          'loss': float(loss.detach())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--hbm-fraction', type=float, default=0.70,
                     help='--checkpointing hbm: reserved-memory target of the calibration steps (the pool settles ~10 %% of the HBM above it)')
     ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
@@ -228,15 +328,27 @@ def main():
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': fused clip + AdamW kernel over the gradient buckets; 'torch': clip on the buckets + torch.optim.AdamW(fused)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--batches', type=int, default=4, help='distinct synthetic batches (seeded per rank) rotated through the timed region')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='launcher / collective plumbing check without a GPU: gloo backend, a toy CPU network through the same '
+                         'BucketedGradAllReduce; the printed line is marked dry_run and is NOT a measurement')
     ap.add_argument('--all-kernel-events', action='store_true',
                     help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
     ap.add_argument('--event-stride', type=int, default=4, help='bracket a pseudo-random 1-in-n sample of the launches of the dominant kernel with HIP events')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     args = ap.parse_args()
 
+    # N > 1 from a plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run and pass its
+    # exit code on. This happens BEFORE anything touches the GPU (no GPU call above this line): a process that has
+    # initialised HIP must never exec / be replaced, children are the only safe way.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the VividMed hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -247,7 +359,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
     from mmmm_amd import kernels as K, hip
     from mmmm_amd.ddp import BucketedGradAllReduce
@@ -260,9 +371,14 @@ def main():
         opt = FlatAdamW(ddp, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0)
     else:
         opt = torch.optim.AdamW(trainable, lr=5e-5, weight_decay=0.01, fused=True)
-    batch = make_batch(w, tok, args.batch, device, seed=rank)      # resident in HBM before timing
+    # distinct synthetic batches, seeded per rank, all resident in HBM before timing; the steps rotate through them (the mixed
+    # workload draws new text lengths per batch, so sequence-length tables change from step to step as they do in training)
+    batches = [make_batch(w, tok, args.batch, device, seed=1000 * rank + i) for i in range(max(1, args.batches))]
+    it = [0]
 
     def step():
+        batch = batches[it[0] % len(batches)]
+        it[0] += 1
         ddp.zero_grad()
         loss = model.training_step(batch)
         loss.backward()
@@ -349,7 +465,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
-                       'text_tokens': w['text'], 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
+                       'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
                        'gradient_checkpointing': plan, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and

@@ -21,11 +21,14 @@ from dataclasses import dataclass, field
 import torch
 import torch.distributed as dist
 
+from .param import no_weight_decay
 
-@dataclass
+
+@dataclass(eq=False)
 class _Bucket:
     buffer: torch.Tensor
     params: list = field(default_factory=list)
+    decay: bool = True                            # False: every slot is a NoWeightDecayParameter (optim.FlatAdamW)
     pending: int = 0
     launched: bool = False
     work: object = None
@@ -33,6 +36,13 @@ class _Bucket:
 
 
 class BucketedGradAllReduce:
+    """Readiness protocol. A slot is READY when autograd has finished the parameter's AccumulateGrad node, which the engine
+    runs exactly once per backward pass, after EVERY use of the parameter has run its backward — also when all of them
+    handed back `None` because their kernels accumulated straight into the bucket view (functional._lora_wgrad, the fp32
+    weight / bias / norm gradients). So a parameter that is used several times per step (iSAM's box / discriminator heads run
+    once per sample, the mask decoder once per grid group) is counted once, after its last use. The fused kernels' own callback
+    `p._vm_grad_ready(p)` only REGISTERS the stream the kernel ran on; it never counts."""
+
     def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None,
                  force_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
@@ -44,22 +54,27 @@ class BucketedGradAllReduce:
         self.buckets: list[_Bucket] = []
         self._bucket_of: dict[int, int] = {}
         self._next = 0
+        self._ready: set[int] = set()             # ids of the parameters whose slot is final in this step
+        self._step_streams: set = set()           # every stream that produced or joined gradients in this step (finish() joins them)
         self._build(bucket_bytes)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        # fused weight-gradient kernels (functional._lora_wgrad) accumulate straight into the bucket view `p.grad` and
-        # bypass AccumulateGrad; they report the slot through this callback instead of the hook above
+        self._hooks = []
+        self._acc_nodes = []                      # the hooks live on the AccumulateGrad nodes: keep the nodes alive
         for p in self.params:
-            p._vm_grad_ready = self._on_grad
+            acc = p.view_as(p).grad_fn.next_functions[0][0]
+            self._acc_nodes.append(acc)
+            # every use returned None (direct accumulation): older engines skip the post-accumulate hook then
+            self._hooks.append(acc.register_prehook(lambda grads, p=p: self._mark_ready(p) if grads[0] is None else None))
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._mark_ready))
+            p._vm_grad_ready = self._note_stream
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):
-        # reverse registration order ~ the order in which backward produces gradients
-        groups: dict[tuple, list] = {}
-        order: list[tuple] = []
+        # reverse registration order ~ the order in which backward produces gradients; decayed and undecayed parameters
+        # (param.NoWeightDecayParameter) never share a bucket, so the fused AdamW launch of a bucket has ONE decay value
         cur: dict[tuple, tuple[list, int]] = {}
         plan: list[tuple[tuple, list]] = []
         for p in reversed(self.params):
-            key = (p.dtype, p.device)
+            key = (p.dtype, p.device, not no_weight_decay(p))
             lst, size = cur.get(key, ([], 0))
             nbytes = p.numel() * p.element_size()
             if lst and size + nbytes > bucket_bytes:
@@ -70,10 +85,10 @@ class BucketedGradAllReduce:
         for key, (lst, _) in cur.items():
             if lst:
                 plan.append((key, lst))
-        for (dtype, device), lst in plan:
+        for (dtype, device, decay), lst in plan:
             n = sum((p.numel() + 7) // 8 * 8 for p in lst)       # 16-byte aligned slots
             buf = torch.zeros(n, dtype=dtype, device=device)
-            b = _Bucket(buffer=buf, params=lst)
+            b = _Bucket(buffer=buf, params=lst, decay=decay)
             off = 0
             for p in lst:
                 p.grad = buf[off:off + p.numel()].view_as(p)
@@ -87,22 +102,37 @@ class BucketedGradAllReduce:
         return sum(b.buffer.numel() * b.buffer.element_size() for b in self.buckets)
 
     # -- backward hooks -------------------------------------------------------------------------
-    def _on_grad(self, p: torch.Tensor):
+    def _note_stream(self, p: torch.Tensor):
+        """a fused kernel accumulated into p.grad on the current stream (possibly one of several uses of p in this step)"""
+        if p.is_cuda:
+            st = torch.cuda.current_stream(p.device)
+            self.buckets[self._bucket_of[id(p)]].streams.add(st)
+            self._step_streams.add(st)
+
+    def _mark_ready(self, p: torch.Tensor):
+        """autograd has finished p's AccumulateGrad node: every use of p has reported, the slot is final"""
+        if id(p) in self._ready:
+            return
+        self._ready.add(id(p))
         b = self.buckets[self._bucket_of[id(p)]]
         b.pending -= 1
         if p.is_cuda:       # backward nodes run on the stream of their forward (the grounding heads use a side stream)
-            b.streams.add(torch.cuda.current_stream(p.device))
+            st = torch.cuda.current_stream(p.device)
+            b.streams.add(st)
+            self._step_streams.add(st)
         self._launch_ready()
 
     def _launch(self, b: _Bucket):
-        if b.streams:       # the launching stream must see every producer stream's gradient writes
+        if b.buffer.is_cuda:       # the launching stream must see every producer stream's gradient writes
             cur = torch.cuda.current_stream(b.buffer.device)
             for st in b.streams:
                 if st != cur:
                     cur.wait_stream(st)
             b.streams.clear()
+            self._step_streams.add(cur)
         if self.collectives:
-            b.buffer.div_(self.world_size)
+            # SUM now, divide once after the collective (finish): dividing a bf16 bucket before the sum would round every
+            # rank's contribution separately (the reference's DDP averages after the reduction as well)
             b.work = dist.all_reduce(b.buffer, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         b.launched = True
 
@@ -114,7 +144,10 @@ class BucketedGradAllReduce:
 
     # -- step boundary --------------------------------------------------------------------------
     def finish(self):
-        """call after backward: reduces whatever is left (zero-filled slots for unused parameters) and waits"""
+        """call after backward, on the stream that will read the gradients (clip / optimizer): reduces whatever is left
+        (zero-filled slots for unused parameters), waits for the collectives, averages, and joins every stream that wrote a
+        gradient in this step — also when there is no collective (one rank), where nothing else orders the side-stream
+        weight-gradient kernels before the optimizer."""
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1
@@ -122,6 +155,17 @@ class BucketedGradAllReduce:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
+        consumer = None
+        for st in self._step_streams:
+            if consumer is None:
+                consumer = torch.cuda.current_stream(st.device)
+            if st != consumer:
+                consumer.wait_stream(st)
+        self._step_streams.clear()
+        if self.collectives and self.world_size > 1:
+            inv = 1.0 / self.world_size
+            for b in self.buckets:
+                b.buffer.mul_(inv)
 
     def zero_grad(self):
         off_fix = False
@@ -129,6 +173,7 @@ class BucketedGradAllReduce:
             b.buffer.zero_()
             b.pending = len(b.params)
             b.launched = False
+            b.streams.clear()
             for p in b.params:
                 if p.grad is None or p.grad.data_ptr() < b.buffer.data_ptr() or \
                         p.grad.data_ptr() >= b.buffer.data_ptr() + b.buffer.numel() * b.buffer.element_size():
@@ -140,6 +185,8 @@ class BucketedGradAllReduce:
                     p.grad = b.buffer[off:off + p.numel()].view_as(p)
                     off += (p.numel() + 7) // 8 * 8
         self._next = 0
+        self._ready.clear()
+        self._step_streams.clear()
 
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6) -> torch.Tensor:

@@ -21,8 +21,9 @@ _CU_CACHE: dict = {}
 
 
 def cu_seqlens_tensor(lens, device) -> torch.Tensor:
-    """int32 prefix sums of `lens` on `device`, cached per (lens, device): a fresh torch.tensor(..., device=...) is a
-    blocking pageable host->device copy, i.e. a full host/GPU synchronisation in the middle of the forward pass"""
+    """int32 prefix sums of `lens` on `device`, cached per (lens, device); a miss goes through pinned memory and a non-blocking
+    copy (a fresh torch.tensor(..., device=...) is a blocking pageable host->device copy, i.e. a full host/GPU synchronisation
+    in the middle of the forward pass)"""
     key = (tuple(int(n) for n in lens), str(device))
     t = _CU_CACHE.get(key)
     if t is None:
@@ -31,7 +32,12 @@ def cu_seqlens_tensor(lens, device) -> torch.Tensor:
             cu.append(cu[-1] + n)
         if len(_CU_CACHE) > 256:
             _CU_CACHE.clear()
-        t = _CU_CACHE[key] = torch.tensor(cu, dtype=torch.int32, device=device)
+        host = torch.tensor(cu, dtype=torch.int32)
+        if torch.device(device).type == 'cuda':      # pinned + non-blocking: a new length tuple (variable text lengths) must not
+            t = host.pin_memory().to(device, non_blocking=True)       # stall the host in the middle of the forward
+        else:
+            t = host.to(device)
+        _CU_CACHE[key] = t
     return t
 
 

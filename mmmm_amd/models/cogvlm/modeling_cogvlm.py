@@ -23,6 +23,7 @@ from torch.utils.checkpoint import checkpoint
 
 from ... import functional as Fh
 from ... import kernels as K
+from ...param import NoWeightDecayParameter
 from .kv_cache import KVCache
 from ..lora import ActivationBudget, Linear, gated_linear, linear_decode
 from .configuration_cogvlm import CogVLMConfig
@@ -35,7 +36,7 @@ CE_IGNORE_INDEX = -100
 class RMSNorm(nn.Module):
     def __init__(self, hidden_size: int, eps: float = 1e-6):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.weight = NoWeightDecayParameter(torch.ones(hidden_size))      # modeling_cogvlm.py:33
         self.variance_epsilon = eps
 
     def forward(self, x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from ... import functional as Fh
+from ...param import NoWeightDecayParameter
 from ..lora import ActivationBudget, Linear
 from ..resample import Downsample, resample
 
@@ -22,7 +23,7 @@ class ParameterWrapper(nn.Module):
     """mmmm/utils.py:62-77 — a bare parameter exposed as `<name>.weight` so PEFT's modules_to_save can hold it"""
     def __init__(self, weight: torch.Tensor):
         super().__init__()
-        self.weight = nn.Parameter(weight)
+        self.weight = weight if isinstance(weight, nn.Parameter) else nn.Parameter(weight)
 
     @classmethod
     def wrap(cls, module: nn.Module, state_dict: dict, prefix: str):
@@ -38,9 +39,9 @@ class PatchEmbedding(nn.Module):
         super().__init__()
         self.proj = Downsample(config.in_channels, config.hidden_size, config.patch_size, interpolate_2d=True)
         self.pos_embed_shape = tuple(config.pos_embed_shape)
-        self.cls_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size))
-        self.cls_pos_embed = ParameterWrapper(torch.zeros(1, config.hidden_size))
-        self.position_embedding = ParameterWrapper(torch.zeros(1, config.hidden_size, *config.pos_embed_shape))
+        self.cls_embedding = ParameterWrapper(NoWeightDecayParameter(torch.zeros(1, config.hidden_size)))
+        self.cls_pos_embed = ParameterWrapper(NoWeightDecayParameter(torch.zeros(1, config.hidden_size)))
+        self.position_embedding = ParameterWrapper(NoWeightDecayParameter(torch.zeros(1, config.hidden_size, *config.pos_embed_shape)))
         self.pt_pos_embed_shape = tuple(getattr(config, 'pt_pos_embed_shape', config.pos_embed_shape[-2:]))
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
@@ -166,8 +167,8 @@ class EVA2CLIPModel(nn.Module):
         self.patch_embedding = PatchEmbedding(vc)
         self.transformer = Transformer(vc)
         self.linear_proj = GLU(config, in_features=vc.hidden_size)
-        self.boi = nn.Parameter(torch.zeros(1, 1, config.hidden_size))
-        self.eoi = nn.Parameter(torch.zeros(1, 1, config.hidden_size))
+        self.boi = NoWeightDecayParameter(torch.zeros(1, 1, config.hidden_size))
+        self.eoi = NoWeightDecayParameter(torch.zeros(1, 1, config.hidden_size))
 
     def forward(self, image: list[torch.Tensor], patch_size: list[tuple], pool_size_list: list[tuple]) -> list[torch.Tensor]:
         """-> per image [Np + 2, hidden] (boi, pooled patches through the GLU adapter, eoi) — visual.py:192-208"""

@@ -52,6 +52,17 @@ class StepState:
         return (cls.seed * 1000003 + cls.step * 7919 + site * 104729) & 0x7FFFFFFFFFFFFFFF
 
 
+class ParamGeneration:
+    """Bumped by optimizers that update parameters through raw device pointers (optim.FlatAdamW: the fused kernel never moves
+    a tensor's `_version`). Part of the freshness key of every cache derived from parameter values (`Linear.lora_t`), so a
+    cached transpose can never outlive an optimizer step."""
+    value: int = 0
+
+    @classmethod
+    def bump(cls):
+        cls.value += 1
+
+
 class ActivationBudget:
     """How many transformer layers may keep their activations instead of being recomputed in backward.
 
@@ -131,7 +142,7 @@ class Linear(nn.Module):
         """(At, Bt) resident transposed LoRA factors if `LoraTransposes.refresh()` ran after the last in-place
         update of A/B (tensor version counters), else (None, None) and the backward transposes per use."""
         c = self._lora_t
-        if c is not None and c[2] == (self.A._version, self.B._version, self.A.data_ptr(), self.B.data_ptr()):
+        if c is not None and c[2] == (self.A._version, self.B._version, self.A.data_ptr(), self.B.data_ptr(), ParamGeneration.value):
             return c[0], c[1]
         return None, None
 
@@ -197,8 +208,9 @@ class LoraTransposes:
     """Resident K-contiguous copies (A^T [in, r], B^T [r, out]) of every LoRA factor below `root`, refreshed by ONE
     launch (`vm_transpose_batched`) after each optimizer step. The backward of a LoRA linear needs both transposes
     (dx += s·(dy B) A; functional._Linear.backward); doing them per use costs two tiny launches per linear per step
-    (~1.3k launches on the full VividMed model). Staleness is detected through the parameters' version counters, so a
-    forgotten `refresh()` only falls back to the per-use path, never to stale factors."""
+    (~1.3k launches on the full VividMed model). Staleness is detected through the parameters' version counters plus
+    `ParamGeneration` (raw-pointer optimizers), so a forgotten `refresh()` only falls back to the per-use path, never to stale
+    factors."""
 
     def __init__(self, root: nn.Module):
         self.linears = [m for m in root.modules() if isinstance(m, Linear) and m.lora_cfg is not None]
@@ -237,4 +249,4 @@ class LoraTransposes:
             n = min(65534, self.n - i)
             K.transpose_batched(self.desc[i:i + n].contiguous() if i else self.desc, n, self.tiles, self.dtype)
         for m, (At, Bt) in zip(self.linears, self.bufs):
-            m._lora_t = (At, Bt, (m.A._version, m.B._version, m.A.data_ptr(), m.B.data_ptr()))
+            m._lora_t = (At, Bt, (m.A._version, m.B._version, m.A.data_ptr(), m.B.data_ptr(), ParamGeneration.value))

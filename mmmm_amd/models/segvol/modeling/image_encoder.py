@@ -8,6 +8,7 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from .... import functional as Fh
+from ....param import NoWeightDecayParameter
 from ...cogvlm.visual import ParameterWrapper
 from ...lora import Linear
 from ...resample import Downsample, resample
@@ -18,7 +19,7 @@ class PatchEmbeddingBlock(nn.Module):
                  pt_in_channels=None, pt_patch_size=None, pt_pos_embed_shape=None):
         super().__init__()
         self.proj = Downsample(in_channels, hidden_size, patch_size)
-        self.position_embeddings = ParameterWrapper(torch.zeros(1, hidden_size, *pos_embed_shape))
+        self.position_embeddings = ParameterWrapper(NoWeightDecayParameter(torch.zeros(1, hidden_size, *pos_embed_shape)))
         self.pt_in_channels, self.pt_patch_size, self.pt_pos_embed_shape = pt_in_channels, pt_patch_size, pt_pos_embed_shape
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):

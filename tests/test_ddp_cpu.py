@@ -118,3 +118,130 @@ def test_clip_grad_norm_on_buckets_matches_torch():
     torch.testing.assert_close(got, ref_norm, rtol=1e-5, atol=1e-6)
     for p, rp in zip([p for p in net.parameters() if p.requires_grad], ref_params):
         torch.testing.assert_close(p.grad, rp.grad, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Direct accumulation (functional._lora_wgrad and friends): the op adds its weight gradient straight into the bucket view,
+# hands autograd None and calls p._vm_grad_ready(p) — once per USE of the parameter. A parameter used several times per step
+# (iSAM's box / discriminator heads: once per sample) must be counted once, after its LAST use.
+class _DirectLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        w.grad += dy.t() @ x                 # straight into the flat bucket
+        w._vm_grad_ready(w)                  # "this use is done" — NOT "the slot is final"
+        return dy @ w.detach(), None
+
+
+class MultiUseNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.early = torch.nn.Linear(8, 8)
+        self.shared = torch.nn.Parameter(torch.randn(8, 8) * 0.3)      # used 4x per step through the direct path
+        self.late = torch.nn.Linear(8, 8)
+
+    def forward(self, xs):
+        out = 0
+        for x in xs:                         # "one call per sample"
+            out = out + self.late(_DirectLinear.apply(self.early(x), self.shared)).sum()
+        return out
+
+    def forward_ref(self, xs):
+        out = 0
+        for x in xs:
+            out = out + self.late(self.early(x) @ self.shared.t()).sum()
+        return out
+
+
+def _multiuse_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    torch.manual_seed(0)
+    net = MultiUseNet()
+    ddp = BucketedGradAllReduce(net.parameters(), bucket_bytes=64)       # every parameter its own bucket
+    launches = []
+    orig = ddp._launch
+    ddp._launch = lambda b: (launches.append((ddp.buckets.index(b), b.pending, len(ddp._ready))), orig(b))[1]
+    out = {}
+    for step in range(2):
+        ddp.zero_grad()
+        torch.manual_seed(7 + rank + 10 * step)
+        xs = [torch.randn(3, 8) for _ in range(4)]
+        net(xs).backward()
+        ddp.finish()
+        out[step] = {n: p.grad.detach().numpy().copy() for n, p in net.named_parameters()}
+    q.put((rank, out, launches))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_parameter_reporting_ready_several_times_is_reduced_after_its_last_use():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_multiuse_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    res = {r: o for r, o, _ in got}
+    for _, _, launches in got:
+        assert all(pending <= 0 for _, pending, _ in launches), 'a bucket was launched with unreported slots'
+    for step in range(2):
+        ref = None
+        for rank in range(world):
+            torch.manual_seed(0)
+            net = MultiUseNet()
+            torch.manual_seed(7 + rank + 10 * step)
+            xs = [torch.randn(3, 8) for _ in range(4)]
+            net.forward_ref(xs).backward()
+            g = {n: p.grad for n, p in net.named_parameters()}
+            ref = g if ref is None else {n: ref[n] + g[n] for n in g}
+        ref = {n: v / world for n, v in ref.items()}
+        for rank in range(world):
+            for n, v in ref.items():
+                torch.testing.assert_close(torch.from_numpy(res[rank][step][n]), v, rtol=1e-5, atol=1e-6)
+        for n in ref:
+            assert (res[0][step][n] == res[1][step][n]).all()
+
+
+def test_multiuse_parameter_counts_once_single_rank():
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    torch.manual_seed(0)
+    net = MultiUseNet()
+    ddp = BucketedGradAllReduce(net.parameters(), world_size=1, bucket_bytes=64)
+    seen = []
+    orig = ddp._mark_ready
+    ddp._mark_ready = lambda p: (seen.append(id(p)), orig(p))[1]
+    for h in ddp._hooks:
+        h.remove()
+    ddp._hooks = [p.register_post_accumulate_grad_hook(ddp._mark_ready) for p in ddp.params]
+    ddp.zero_grad()
+    net([torch.randn(3, 8) for _ in range(4)]).backward()
+    b = ddp.buckets[ddp._bucket_of[id(net.shared)]]
+    assert b.pending == 0 and id(net.shared) in ddp._ready
+    ddp.finish()
+    assert all(bk.pending == 0 for bk in ddp.buckets)
+
+
+def test_no_weight_decay_parameters_get_their_own_buckets():
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.param import NoWeightDecayParameter
+    m = torch.nn.Module()
+    m.a = torch.nn.Parameter(torch.zeros(10))
+    m.gain = NoWeightDecayParameter(torch.ones(10))
+    m.b = torch.nn.Parameter(torch.zeros(10))
+    ddp = BucketedGradAllReduce(m.parameters(), world_size=1)
+    assert sorted((b.decay, len(b.params)) for b in ddp.buckets) == [(False, 1), (True, 2)]
+    assert ddp.buckets[ddp._bucket_of[id(m.gain)]].decay is False

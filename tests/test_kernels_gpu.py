@@ -627,6 +627,91 @@ def test_flat_adamw_with_clipping_matches_torch(dev, K, dt):
     ddp.remove()
 
 
+def test_flat_adamw_param_groups_schedule_and_resume_match_torch(dev, K):
+    """the reference's optimizer set-up (conf/phase-vg/fit.yaml:25-42): AdamW with a decayed and an undecayed
+    (NoWeightDecayParameter) group, learning rate from the warm-up + cosine schedule stepped every `frequency` steps; plus
+    checkpoint / resume through a torch.optim.AdamW-layout state dict, in both directions."""
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.optim import FlatAdamW, CosineLRSchedule
+    from mmmm_amd.param import NoWeightDecayParameter
+    torch.manual_seed(1)
+    shapes = [(64, 96), (96,), (40, 8), (8,), (128, 64)]
+    nodecay = [False, True, False, True, False]
+    mk = lambda s, nd: (NoWeightDecayParameter if nd else torch.nn.Parameter)(torch.randn(s, device=dev))
+    mine = [mk(s, nd) for s, nd in zip(shapes, nodecay)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    sched = CosineLRSchedule(2e-3, t_initial=20, warmup_t=6, warmup_prefix=True, frequency=3)
+    ddp = BucketedGradAllReduce(mine, world_size=1, bucket_bytes=16384)
+    opt = FlatAdamW(ddp, lr=sched, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0)
+    groups = [{'params': [r for r, nd in zip(ref, nodecay) if not nd], 'weight_decay': 0.1},
+              {'params': [r for r, nd in zip(ref, nodecay) if nd], 'weight_decay': 0.0}]
+    ropt = torch.optim.AdamW(groups, lr=2e-3, betas=(0.9, 0.95))
+
+    def one_step(opt_, it):
+        ddp.zero_grad()
+        g = torch.Generator(device=dev).manual_seed(100 + it)
+        grads = [torch.randn(s, device=dev, generator=g) * (2.0 if it % 2 else 0.02) for s in shapes]
+        for p, r, gr in zip(mine, ref, grads):
+            p.grad.copy_(gr)
+            r.grad = gr.clone()
+        ddp.finish()
+        lr = sched(it)
+        assert opt_.current_lr() == lr
+        opt_.step()
+        for grp in ropt.param_groups:
+            grp['lr'] = lr
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+
+    for it in range(8):
+        one_step(opt, it)
+    assert sched(0) == 0.0 and sched(2) == 0.0 and sched(3) > 0          # constructor value holds for the first `frequency` steps
+    for p, r in zip(mine, ref):
+        assert rel_err(p, r) < 3e-6
+    # resume: FlatAdamW state -> a fresh FlatAdamW, and -> torch.optim.AdamW (same layout)
+    sd = opt.state_dict()
+    assert [len(g['params']) for g in sd['param_groups']] == [3, 2] and [g['weight_decay'] for g in sd['param_groups']] == [0.1, 0.0]
+    ddp.remove()
+    mine2 = [mk(s, nd) for s, nd in zip(shapes, nodecay)]
+    with torch.no_grad():
+        for a, b in zip(mine2, mine):
+            a.copy_(b)
+    ddp2 = BucketedGradAllReduce(mine2, world_size=1, bucket_bytes=16384)
+    opt2 = FlatAdamW(ddp2, lr=sched, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 8
+    rsd = ropt.state_dict()
+    opt3_params = [mk(s, nd) for s, nd in zip(shapes, nodecay)]
+    with torch.no_grad():
+        for a, b in zip(opt3_params, ref):
+            a.copy_(b)
+    ddp3 = BucketedGradAllReduce(opt3_params, world_size=1, bucket_bytes=16384)
+    opt3 = FlatAdamW(ddp3, lr=sched, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0)
+    opt3.load_state_dict(rsd)                                            # a torch.optim.AdamW checkpoint loads too
+    mine_saved, ddp_saved = mine, ddp
+    for trial_params, trial_ddp, trial_opt in ((mine2, ddp2, opt2), (opt3_params, ddp3, opt3)):
+        ref_c = [torch.nn.Parameter(r.detach().clone()) for r in ref]
+        ropt_c = torch.optim.AdamW([{'params': [r for r, nd in zip(ref_c, nodecay) if not nd], 'weight_decay': 0.1},
+                                    {'params': [r for r, nd in zip(ref_c, nodecay) if nd], 'weight_decay': 0.0}], lr=2e-3, betas=(0.9, 0.95))
+        ropt_c.load_state_dict(rsd)
+        for it in range(8, 11):
+            trial_ddp.zero_grad()
+            g = torch.Generator(device=dev).manual_seed(100 + it)
+            grads = [torch.randn(s, device=dev, generator=g) for s in shapes]
+            for p, r, gr in zip(trial_params, ref_c, grads):
+                p.grad.copy_(gr)
+                r.grad = gr.clone()
+            trial_ddp.finish()
+            trial_opt.step()
+            for grp in ropt_c.param_groups:
+                grp['lr'] = sched(it)
+            torch.nn.utils.clip_grad_norm_(ref_c, 1.0)
+            ropt_c.step()
+        for p, r in zip(trial_params, ref_c):
+            assert rel_err(p, r) < 3e-6
+        trial_ddp.remove()
+
+
 def test_lsap_matches_scipy(dev, K):
     """device Hungarian matching == scipy.optimize.linear_sum_assignment, bit-exact, ties included: random float costs,
     small-integer costs (many optimal assignments), constant matrices, duplicated columns (the dummy negative columns of
