@@ -19,6 +19,25 @@ from . import ref_shims
 OUT = Path(__file__).resolve().parents[1] / 'tests' / 'golden'
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def zero_filled_empty():
+    """The reference leaves the padded rows of several activations UNINITIALISED (`torch.empty` at modeling_cogvlm.py:277 and in
+    attention_fn; rows outside the padding mask are never written). Their content never reaches a valid row, but 0 x garbage
+    does reach weight gradients (a NaN bit pattern in a padded row of the last hidden state turns the whole lm_head gradient
+    into NaN: seen while generating f13). Inside this context `torch.empty*` returns zeros, which is one legal outcome of
+    "uninitialised" and makes the fixtures reproducible."""
+    e, el = torch.empty, torch.empty_like
+    torch.empty = lambda *a, **k: e(*a, **k).zero_()
+    torch.empty_like = lambda *a, **k: el(*a, **k).zero_()
+    try:
+        yield
+    finally:
+        torch.empty, torch.empty_like = e, el
+
+
 def randomize_(module: torch.nn.Module, seed: int):
     """explicit, non-degenerate values for every parameter/buffer (norm weights near 1, nothing at zero)"""
     g = torch.Generator().manual_seed(seed)
@@ -341,6 +360,7 @@ def f10_state_dict_adapters(R):
     # 4. mask decoder: per-voxel LayerNorm affine + shorter mask-token table
     md_mod = sys.modules['mmmm.models.segvol.modeling.mask_decoder']
     tr = sys.modules['mmmm.models.segvol.modeling.transformer']
+    torch.manual_seed(1010)          # the embedding tables' own init is part of the fixture (init_tokens): make it reproducible
     dec = md_mod.MaskDecoder(transformer_dim=16, transformer=tr.TwoWayTransformer(depth=1, embedding_dim=16, mlp_dim=32, num_heads=2),
                              num_instances=6)
     init_tokens = dec.mask_tokens.weight.detach().clone()
@@ -449,16 +469,183 @@ def f12_generation(R):
     ), OUT / 'f12_generation.pt')
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# bf16-true fixtures: the reference's own training precision (conf/phase-vg/fit.yaml:7 `precision: bf16-true`,
+# mmmm.py:468-492 MyPrecision) run on the CPU. They separate "rounds where the reference rounds" (testable, tight) from
+# "differs from an fp32 evaluation by bf16 rounding" (physics), and give the bf16 tolerance of the GPU tests its evidence.
+def f13_bf16_true(R):
+    g = torch.Generator().manual_seed(13)
+    res = {}
+    # (a) tiny CogVLM of F5 (same weights, same inputs) converted with .bfloat16()
+    f5 = torch.load(OUT / 'f5_tiny_lm.pt', weights_only=False)
+    m, cfg = build_tiny_model(R, False, seed=50)
+    m.load_state_dict(f5['state_dict'])
+    m.train()
+    m = m.bfloat16()
+    images = [im.bfloat16() for im in f5['images']]
+    vi = dict(f5['vlm_inputs'])
+    vi['weight'] = vi['weight'].bfloat16()          # HalfPrecision.convert_input casts every floating-point input
+    out = m(**vi, image=images, patch_size=f5['patch_size'], pool_size=f5['pool_size'], return_dict=True, output_hidden_states=True)
+    out.loss.backward()
+    params = dict(m.named_parameters())
+    am = vi['attention_mask'].bool()
+    res['tiny_lm'] = dict(
+        logits=out.logits.detach(), loss=out.loss.detach(),
+        hidden_states=[torch.where(am[..., None], h.detach(), torch.zeros((), dtype=h.dtype)) for h in out.hidden_states],   # padded rows: uninitialised
+        grads={n: params[n].grad.clone() for n in f5['grads']},
+        note='weights / inputs = f5_tiny_lm.pt rounded to bf16; logits are fp32 (the reference casts them, modeling_cogvlm.py:701)')
+    # (b) training_step of F8 under MyPrecision (sam / isam_model / vg_proj stay fp32; grounding_image / boxes stay fp32)
+    f8 = torch.load(OUT / 'f8_training_step.pt', weights_only=False)
+    m, cfg = build_tiny_model(R, True, seed=80)
+    m.load_state_dict(f8['state_dict'])
+    m.train()
+    prec = R.mmmm.MyPrecision()
+    m = prec.convert_module(m)
+    assert m.sam.image_encoder.blocks[0].attn.qkv.weight.dtype == torch.float32 and m.lm_head.weight.dtype == torch.bfloat16
+    batch = prec.convert_input(f8['batch'])
+    assert batch['grounding_image'][0].dtype == torch.float32 and batch['image'][0].dtype == torch.bfloat16
+    loss = m.training_step(batch)
+    loss.backward()
+    params = dict(m.named_parameters())
+    res['training_step'] = dict(loss=loss.detach(), logged={k: (v.detach() if torch.is_tensor(v) else v) for k, v in m._logged.items()},
+                                grads={n: params[n].grad.clone() for n in f8['grads'] if params[n].grad is not None})
+    torch.save(res, OUT / 'f13_bf16_true.pt')
+
+
+def spec_tensor(name: str, shape, scale: float, dtype=torch.float32) -> torch.Tensor:
+    """Seed-free weights for the true-width fixtures: element i of tensor `name` is a closed-form function of (name, i), so the
+    400 M parameters of a true-width layer need not be stored: u = frac(sin(i * 12.9898 + salt) * 43758.5453) in float64,
+    value = (2u - 1) * scale * sqrt(3) (variance scale^2). Restated identically in tests/_tiny.py:spec_tensor."""
+    import zlib
+    n = math.prod(shape)
+    salt = float(zlib.crc32(name.encode()) % 10007)
+    i = torch.arange(n, dtype=torch.float64)
+    u = torch.sin(i * 12.9898 + salt * 78.233) * 43758.5453
+    u = u - torch.floor(u)
+    return ((2 * u - 1) * (scale * math.sqrt(3.0))).to(dtype).reshape(shape)
+
+
+def f2_true_width(R):
+    """ONE decoder layer, ONE ViT layer at the true widths (h=4096 / i=11008 / 32 heads of 128; d=1792 / f=15360 / 16
+    heads of 112) and the 768-wide two-way transformer block of SAM (F6), run by the reference in fp32 AND in bf16. Weights come from
+    `spec_tensor` (the fixture stores the spec + checksums, inputs, outputs, the input gradient and slices of weight gradients)."""
+    mc, vis = R.modeling_cogvlm, R.visual
+    import sys
+    tr = sys.modules['mmmm.models.segvol.modeling.transformer']
+    res = {}
+    g = torch.Generator().manual_seed(2)
+
+    def fill(module, prefix, scales):
+        sums = {}
+        with torch.no_grad():
+            for n, p_ in module.named_parameters():
+                leaf = n.rsplit('.', 1)[-1]
+                if leaf == 'weight' and p_.ndim == 1:
+                    t = 1 + spec_tensor(prefix + n, p_.shape, 0.1)
+                elif leaf == 'bias':
+                    t = spec_tensor(prefix + n, p_.shape, 0.02)
+                else:
+                    t = spec_tensor(prefix + n, p_.shape, scales(n, p_))
+                p_.copy_(t)
+                sums[n] = float(t.double().sum())
+        return sums
+
+    # ---- decoder layer: L = 40 (14 vision-expert tokens), batch 2 with right padding on sample 1; inputs from spec_tensor as well
+    cfg = R.config.CogVLMConfig()          # true widths are the defaults: 4096 / 11008 / 32 heads
+    cfg.num_hidden_layers = 1
+    layer = mc.CogVLMDecoderLayer(cfg)
+    sums = fill(layer, 'dec.', lambda n, p_: 1.0 / math.sqrt(p_.shape[1]))
+    B, L, h = 2, 40, cfg.hidden_size
+    x = spec_tensor('dec.x', (B, L, h), 0.5)
+    tt = torch.zeros(B, L, dtype=torch.long)
+    tt[:, 1:15] = 1
+    am = torch.ones(B, L, dtype=torch.long)
+    am[1, 33:] = 0
+    pos = torch.cat([torch.tensor([0, 1]), torch.full((12,), 2), torch.tensor([3, 4]), torch.arange(5, 5 + L - 16)])[None].repeat(B, 1)
+    gy = spec_tensor('dec.gy', (B, L, h), 1.0) * am[..., None]
+    watch = ['self_attn.vision_expert_query_key_value.weight', 'mlp.language_mlp.down_proj.weight', 'input_layernorm.weight']
+
+    def run_dec(dtype):
+        lay = layer.to(dtype)
+        lay.self_attn.rotary_emb.max_seq_len_cached = 0      # as in training: the table is first built AFTER the precision conversion
+        for p_ in lay.parameters():
+            p_.grad = None
+        xx = x.detach().to(dtype).clone().requires_grad_()
+        y = lay(xx, tt, pos, am.bool())[0]
+        y = torch.where(am.bool()[..., None], y, torch.zeros((), dtype=dtype))      # padded rows are uninitialised memory in the reference
+        (y.float() * gy).sum().backward()
+        ps = dict(lay.named_parameters())
+        return dict(y=y.detach().clone(), dx=torch.where(am.bool()[..., None], xx.grad, torch.zeros((), dtype=dtype)),
+                    wgrad_rows={n: ps[n].grad.float().reshape(ps[n].shape[0], -1)[:8].clone() for n in watch},
+                    wgrad_norm={n: float(ps[n].grad.double().norm()) for n in watch})
+    res['decoder_layer'] = dict(shape=(B, L, h), token_type_ids=tt, attention_mask=am, position_ids=pos, param_sums=sums,
+                                input_sums=dict(x=float(x.double().sum()), gy=float(gy.double().sum())),
+                                fp32=run_dec(torch.float32))
+    res['decoder_layer']['bf16'] = run_dec(torch.bfloat16)
+    del layer
+
+    # ---- ViT layer: two packed sequences (one 3-D-sized 2049-token sequence would make the fixture 15 MB; 97 + 40 tokens cover the
+    # block-diagonal mask at hd = 112; the Nv = 2049 case is an oracle comparison on the GPU, tests/test_model_gpu.py)
+    from argparse import Namespace
+    # EVA2-CLIP-E widths (THUDM/cogvlm-chat-hf config.json: the reference reads them from the checkpoint's config)
+    vc = Namespace(in_channels=3, hidden_size=1792, num_heads=16, num_hidden_layers=1, intermediate_size=15360, hidden_act='gelu',
+                   dropout_prob=0.0, layer_norm_eps=1e-6)
+    vl = vis.TransformerLayer(vc)
+    vsums = fill(vl, 'vit.', lambda n, p_: 1.0 / math.sqrt(p_.shape[1]))
+    lens = [97, 40]
+    xv = spec_tensor('vit.x', (1, sum(lens), vc.hidden_size), 0.5)
+    gv = spec_tensor('vit.gy', (1, sum(lens), vc.hidden_size), 1.0)
+    from xformers.ops.fmha import BlockDiagonalMask
+    vwatch = ['attention.query_key_value.weight', 'mlp.fc2.weight', 'post_attention_layernorm.weight']
+
+    def run_vit(dtype):
+        lay = vl.to(dtype)
+        for p_ in lay.parameters():
+            p_.grad = None
+        xx = xv.detach().to(dtype).clone().requires_grad_()
+        y = lay(xx, BlockDiagonalMask(lens))
+        (y.float() * gv).sum().backward()
+        ps = dict(lay.named_parameters())
+        return dict(y=y.detach()[0].clone(), dx=xx.grad[0].clone(),
+                    wgrad_rows={n: ps[n].grad.float().reshape(ps[n].shape[0], -1)[:8].clone() for n in vwatch},
+                    wgrad_norm={n: float(ps[n].grad.double().norm()) for n in vwatch})
+    res['vit_layer'] = dict(lens=lens, param_sums=vsums, input_sums=dict(x=float(xv.double().sum()), gy=float(gv.double().sum())),
+                            fp32=run_vit(torch.float32))
+    res['vit_layer']['bf16'] = run_vit(torch.bfloat16)
+    del vl
+
+    # ---- SAM two-way block at 768 (8 heads, mlp 2048) on an [8,16,16]-sized key set is 2048 keys x 768; fixture uses the 3-D grid
+    # 128 keys to stay small, 7 query tokens, 2 prompts. fp32 only (the heads are fp32 islands).
+    blk = tr.TwoWayAttentionBlock(embedding_dim=768, num_heads=8, mlp_dim=2048, skip_first_layer_pe=False)
+    bsums = fill(blk, 'twoway.', lambda n, p_: 1.0 / math.sqrt(p_.shape[1]))
+    nq, nk, P_ = 7, 128, 2
+    queries = spec_tensor('twoway.queries', (P_, nq, 768), 1.0).requires_grad_()
+    keys = spec_tensor('twoway.keys', (P_, nk, 768), 1.0).requires_grad_()
+    qpe = spec_tensor('twoway.qpe', (P_, nq, 768), 1.0)
+    kpe = spec_tensor('twoway.kpe', (P_, nk, 768), 1.0)
+    q2, k2 = blk(queries, keys, qpe, kpe)
+    (q2.square().mean() + k2.square().mean()).backward()
+    res['two_way_block'] = dict(shape=(P_, nq, nk, 768), param_sums=bsums,
+                                input_sums=dict(queries=float(queries.double().sum()), keys=float(keys.double().sum())),
+                                q_out=q2.detach(), k_out=k2.detach(), dq=queries.grad.clone(), dk=keys.grad.clone())
+    torch.save(res, OUT / 'f2_true_width.pt')
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shims.load()
     only = os.environ.get('GOLDEN_ONLY')
-    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters, f11_vlm_inputs, f12_generation):
+    for fn in (f1_masks, f3_units, f4_vit_identity, f5_tiny_lm, f6_sam, f7_losses, f8_training_step, f9_lora_targets, f10_state_dict_adapters, f11_vlm_inputs, f12_generation,
+               f13_bf16_true, f2_true_width):
         if only and only not in fn.__name__:
             continue
-        fn(R)
+        if fn in (f13_bf16_true, f2_true_width):
+            with zero_filled_empty():
+                fn(R)
+        else:
+            fn(R)
         print('wrote', fn.__name__)
     for p in sorted(OUT.glob('*.pt')):
         print(p.name, os.path.getsize(p) // 1024, 'KiB')

@@ -1,0 +1,173 @@
+"""Pins the oracle at the TRUE layer widths and in the reference's own training precision (bf16-true), against fixtures produced
+by the reference itself (oracle/make_golden.py: f2_true_width, f13_bf16_true).
+
+fp32: tolerance 1e-5 as everywhere else. bf16: two bf16 evaluations of one layer are only reproducible to a few 1e-3 — every op
+re-rounds to 8 mantissa bits, and a different summation order flips last bits that the next op amplifies — so the bound is stated
+relative to the reference's OWN bf16 error e_ref = |ref_bf16 - ref_fp32| / |ref_fp32| stored in the fixture:
+    |oracle_bf16 - ref_fp32| <= 1.25 e_ref     (the restatement is as accurate as the reference's bf16 run)
+    |oracle_bf16 - ref_bf16| <= 1.5 e_ref      (two runs with independent rounding noise differ by ~sqrt(2) e_ref)
+The GPU tests (tests/test_model_gpu.py) apply the same two inequalities to the HIP path."""
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import vividmed as O
+from tests import _tiny
+
+G = Path(__file__).parent / 'golden'
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope='module')
+def f2():
+    return torch.load(G / 'f2_true_width.pt', weights_only=False)
+
+
+TRUE_CFG = O.Cfg(vocab_size=32008, hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32,
+                 vision=O.VisionCfg(hidden_size=1792, num_heads=16, num_hidden_layers=1, intermediate_size=15360, layer_norm_eps=1e-6))
+
+
+def _leaf(t, dt, grad=True):
+    return t.detach().to(dt).clone().requires_grad_(grad)
+
+
+def run_decoder(f2, dt):
+    d = f2['decoder_layer']
+    B, L, h = d['shape']
+    watch = tuple(d['fp32']['wgrad_rows'])
+    sd = {'l.' + k: _leaf(v, dt, k in watch) for k, v in _tiny.spec_state('dec.', _tiny.decoder_layer_shapes(), d['param_sums']).items()}
+    am = d['attention_mask']
+    x = _tiny.spec_tensor('dec.x', (B, L, h), 0.5)
+    gy = _tiny.spec_tensor('dec.gy', (B, L, h), 1.0) * am[..., None]
+    assert abs(float(x.double().sum()) - d['input_sums']['x']) < 1e-6 * abs(d['input_sums']['x']) + 1e-9
+    cos, sin = O.rope_tables(128, int(d['position_ids'].max()) + 1, dt)          # bf16-true: the table is built in bf16
+    xx = _leaf(x, dt)
+    y = O.decoder_layer(sd, TRUE_CFG, 'l', xx, d['token_type_ids'], d['position_ids'], am.bool(), cos, sin)
+    (y.float() * gy).sum().backward()
+    return dict(y=y, dx=xx.grad * am[..., None].to(dt), wgrad_rows={n: sd['l.' + n].grad.float().reshape(sd['l.' + n].shape[0], -1)[:8] for n in watch},
+                wgrad_norm={n: float(sd['l.' + n].grad.double().norm()) for n in watch})
+
+
+def run_vit(f2, dt):
+    v = f2['vit_layer']
+    lens = v['lens']
+    T = sum(lens)
+    watch = tuple(v['fp32']['wgrad_rows'])
+    sd = {'l.' + k: _leaf(t, dt, k in watch) for k, t in _tiny.spec_state('vit.', _tiny.vit_layer_shapes(), v['param_sums']).items()}
+    x = _tiny.spec_tensor('vit.x', (1, T, 1792), 0.5)[0]
+    gy = _tiny.spec_tensor('vit.gy', (1, T, 1792), 1.0)[0]
+    xx = _leaf(x, dt)
+    y = O.vit_layer(sd, TRUE_CFG, 'l', xx, lens)
+    (y.float() * gy).sum().backward()
+    return dict(y=y, dx=xx.grad, wgrad_rows={n: sd['l.' + n].grad.float().reshape(sd['l.' + n].shape[0], -1)[:8] for n in watch},
+                wgrad_norm={n: float(sd['l.' + n].grad.double().norm()) for n in watch})
+
+
+def check_fp32(got, ref, tol=1e-5):
+    assert rel(got['y'], ref['y']) < tol and rel(got['dx'], ref['dx']) < tol
+    for n, r in ref['wgrad_rows'].items():
+        assert rel(got['wgrad_rows'][n], r) < tol, n
+        assert abs(got['wgrad_norm'][n] / ref['wgrad_norm'][n] - 1) < tol, n
+
+
+def check_bf16(got, ref16, ref32, what):
+    """the two inequalities of the module docstring, for the output, the input gradient and the stored weight-gradient rows"""
+    report = {}
+    for key in ('y', 'dx'):
+        e_ref = rel(ref16[key].float(), ref32[key])
+        e_got, d = rel(got[key].float(), ref32[key]), rel(got[key].float(), ref16[key].float())
+        report[key] = (e_ref, e_got, d)
+        assert e_got <= 1.25 * e_ref and d <= 1.5 * e_ref, (what, key, e_ref, e_got, d)
+    for n, r32 in ref32['wgrad_rows'].items():
+        e_ref = rel(ref16['wgrad_rows'][n], r32)
+        e_got, d = rel(got['wgrad_rows'][n], r32), rel(got['wgrad_rows'][n], ref16['wgrad_rows'][n])
+        report[n] = (e_ref, e_got, d)
+        assert e_got <= 1.25 * e_ref and d <= 1.5 * e_ref, (what, n, e_ref, e_got, d)
+    return report
+
+
+def test_true_width_decoder_layer_fp32_and_bf16(f2):
+    d = f2['decoder_layer']
+    check_fp32(run_decoder(f2, torch.float32), d['fp32'])
+    check_bf16(run_decoder(f2, torch.bfloat16), d['bf16'], d['fp32'], 'decoder layer')
+
+
+def test_true_width_vit_layer_fp32_and_bf16(f2):
+    v = f2['vit_layer']
+    check_fp32(run_vit(f2, torch.float32), v['fp32'])
+    check_bf16(run_vit(f2, torch.bfloat16), v['bf16'], v['fp32'], 'ViT layer')
+
+
+def test_two_way_block_768_fp32(f2):
+    t = f2['two_way_block']
+    P_, nq, nk, c = t['shape']
+    sd = {'b.' + k: w for k, w in _tiny.spec_state('twoway.', _tiny.two_way_block_shapes(), t['param_sums']).items()}
+    q = _tiny.spec_tensor('twoway.queries', (P_, nq, c), 1.0).requires_grad_()
+    k = _tiny.spec_tensor('twoway.keys', (P_, nk, c), 1.0).requires_grad_()
+    qpe, kpe = _tiny.spec_tensor('twoway.qpe', (P_, nq, c), 1.0), _tiny.spec_tensor('twoway.kpe', (P_, nk, c), 1.0)
+    q2, k2 = O.two_way_block(sd, 'b', q, k, qpe, kpe, 8, False)
+    (q2.square().mean() + k2.square().mean()).backward()
+    for got, ref in ((q2, t['q_out']), (k2, t['k_out']), (q.grad, t['dq']), (k.grad, t['dk'])):
+        assert rel(got, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tiny full model / training step in bf16-true (fixture f13: the reference converted by .bfloat16() / MyPrecision)
+def to_bf16_true(sd: dict, fp32_prefixes=('sam.', 'isam_model.', 'vg_proj.')) -> dict:
+    """MyPrecision.convert_module (mmmm.py:481-492): everything bf16 except the fp32 children"""
+    return {k: (v if (not v.is_floating_point() or k.startswith(fp32_prefixes)) else v.bfloat16()) for k, v in sd.items()}
+
+
+def lm_bf16(f5):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in to_bf16_true(f5['state_dict']).items()}
+    vi = f5['vlm_inputs']
+    out = O.causal_lm_forward(sd, _tiny.lm_cfg(), vi['input_ids'], image=[im.bfloat16() for im in f5['images']], patch_size=f5['patch_size'],
+                              pool_size=f5['pool_size'], token_type_ids=vi['token_type_ids'], attention_mask=vi['attention_mask'],
+                              position_ids=vi['position_ids'], labels=vi['labels'], weight=vi['weight'].bfloat16())
+    return sd, out
+
+
+def test_f13_tiny_lm_bf16_true():
+    f5 = torch.load(G / 'f5_tiny_lm.pt', weights_only=False)
+    r16 = torch.load(G / 'f13_bf16_true.pt', weights_only=False)['tiny_lm']
+    sd, out = lm_bf16(f5)
+    out.loss.backward()
+    am = f5['vlm_inputs']['attention_mask'].bool()
+    pairs = {'logits': (out.logits[am], r16['logits'][am], f5['logits'][am]), 'loss': (out.loss, r16['loss'], f5['loss'])}
+    for i, (a, b, c) in enumerate(zip(out.hidden_states, r16['hidden_states'], f5['hidden_states'])):
+        pairs[f'hidden{i}'] = ((a * am[..., None]).float(), b.float(), c)
+    for n in f5['grads']:
+        pairs['grad ' + n] = (sd[n].grad.float(), r16['grads'][n].float(), f5['grads'][n])
+    for name, (got, ref16, ref32) in pairs.items():
+        e_ref, e_got, d = rel(ref16, ref32), rel(got, ref32), rel(got, ref16)
+        if name == 'hidden0':        # the embedding lookup + image scatter: no arithmetic beyond the vision tower's
+            assert d <= max(1.5 * e_ref, 1e-6), (name, e_ref, d)
+            continue
+        assert e_got <= 1.3 * e_ref + 1e-4 and d <= 1.5 * e_ref + 1e-4, (name, e_ref, e_got, d)
+
+
+def test_f13_training_step_bf16_true():
+    f8 = torch.load(G / 'f8_training_step.pt', weights_only=False)
+    r16 = torch.load(G / 'f13_bf16_true.pt', weights_only=False)['training_step']
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in to_bf16_true(f8['state_dict']).items()}
+    b = dict(f8['batch'])
+    b['image'] = [im.bfloat16() for im in b['image']]
+    b['vlm_inputs'] = dict(b['vlm_inputs'], weight=b['vlm_inputs']['weight'].bfloat16())
+    loss, log = O.training_step(sd, _tiny.step_cfg(), b)
+    loss.backward()
+    for k, ref16 in r16['logged'].items():
+        if not torch.is_tensor(ref16) or not ref16.is_floating_point():
+            continue
+        ref32 = f8['logged'][k]
+        e_ref = rel(ref16, ref32)
+        # one number, not a norm over many: its error does not average, so the bound carries an absolute floor
+        assert rel(log[k], ref32) <= 3 * e_ref + 5e-3 and rel(log[k], ref16) <= 3 * e_ref + 5e-3, (k, e_ref, float(log[k]), float(ref16), float(ref32))
+    for n, g16 in r16['grads'].items():
+        g32 = f8['grads'][n]
+        e_ref, e_got, d = rel(g16.float(), g32), rel(sd[n].grad.float(), g32), rel(sd[n].grad.float(), g16.float())
+        assert e_got <= 1.3 * e_ref + 1e-4 and d <= 1.5 * e_ref + 1e-4, (n, e_ref, e_got, d)
