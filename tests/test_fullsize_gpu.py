@@ -1,4 +1,6 @@
-"""BASELINE configs[1] at FULL size (CogVLM-7B, 32 decoder + 63 ViT-E layers, SAM-B + iSAM unfrozen, LoRA r64 with dropout, bf16;
+"""Every BASELINE config at FULL size on the HIP path — configs[1] phase-vg 448x448, configs[2] phase-vlm mixed 2-D / 3-D batch with
+variable text length, configs[3] phase-grg 32x256x256, configs[4] model-hr 896x896 and 64x384x384 (test_every_*_config_* below).
+Description of the first and most detailed of them — BASELINE configs[1] at FULL size (CogVLM-7B, 32 decoder + 63 ViT-E layers, SAM-B + iSAM unfrozen, LoRA r64 with dropout, bf16;
 batch 2 to keep the test short): the oracle cannot run this size, so parity is checked through size-independent properties:
 
   * replay: the same step twice from the same state gives the same loss to 2e-6 (usually bit-identical; dropout masks are a pure function of
@@ -28,7 +30,15 @@ def _build(dev, workload):
     trainable = [p for p in model.parameters() if p.requires_grad]
     ddp = BucketedGradAllReduce(trainable, world_size=1)
     batch = bench.make_batch(w, tok, 2, dev, seed=11)
+    model._test_tok = tok
     return model, ddp, batch
+
+
+def _batch_for(model, workload, dev, seed=11):
+    """a batch of two samples of another workload for an already built model (the architecture is the same for every config:
+    only image / token shapes differ)"""
+    import bench
+    return bench.make_batch(bench.WORKLOADS[workload], model._test_tok, 2, dev, seed=seed)
 
 
 @pytest.fixture
@@ -86,6 +96,101 @@ def same_loss(a, b):
 def rel(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _permuted(batch):
+    perm = {k: ([v[1], v[0]] if isinstance(v, list) else v) for k, v in batch.items()}
+    perm['vlm_inputs'] = {k: v.flip(0) for k, v in batch['vlm_inputs'].items()}
+    perm['host'] = dict(input_ids=batch['host']['input_ids'].flip(0), index_offsets=batch['host']['index_offsets'][::-1])
+    return perm
+
+
+def _without_dropout(model):
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        cfgs = {id(m.lora_cfg): m.lora_cfg for m in model.modules() if getattr(m, 'lora_cfg', None) is not None}
+        saved = {k: c.lora_dropout for k, c in cfgs.items()}
+        for c in cfgs.values():
+            c.lora_dropout = 0.0
+        try:
+            yield
+        finally:
+            for k, c in cfgs.items():
+                c.lora_dropout = saved[k]
+    return ctx()
+
+
+@pytest.mark.parametrize('workload', ['phase-grg-3d', 'model-hr-2d', 'model-hr-3d'])
+def test_every_grounding_config_at_full_size(dev, full, workload):
+    """BASELINE configs[3] (phase-grg: 3-D CT 32x256x256, SAM + iSAM unfrozen) and configs[4] (model-hr: 896x896 2-D and 64x384x384
+    3-D; bf16 here) through the full-depth HIP path, batch 2 (one semantic, one instance sample): finite loss and gradients for
+    every trainable parameter, replay, recompute-every-layer == keep-within-budget, sample permutation. What these shapes add
+    over configs[1]: 2 049 / 3 137 / 4 609-token ViT sequences, the z-folded patch embedding (pz 4 / 8), 3-D SAM grids
+    ([8,16,16] and [8,24,24]) with the z-collapsing up-sampler, position tables resampled to non-cubic grids."""
+    model, ddp, _ = full
+    batch = _batch_for(model, workload, dev)
+    budget = 120 << 30
+    l0, g0 = run_step(model, ddp, batch, 7, budget)
+    assert torch.isfinite(l0) and all(torch.isfinite(g).all() for g in g0.values())
+    assert all(g0[n].norm() > 0 for n in g0 if n.startswith(('lm_head.', 'vg_proj.')))
+    l1, g1 = run_step(model, ddp, batch, 7, budget)
+    assert same_loss(l0, l1)
+    same_gradients(g1, g0)
+    l3, g3 = run_step(model, ddp, batch, 7, None)            # the reference's mode: every layer recomputed
+    assert same_loss(l0, l3)
+    same_gradients(g3, g0)
+    with _without_dropout(model):
+        a, _ = run_step(model, ddp, batch, 7, budget)
+        b, _ = run_step(model, ddp, _permuted(batch), 7, budget)
+    assert abs(a.item() - b.item()) / abs(a.item()) < 2e-3, (a.item(), b.item())
+
+
+def test_mixed_2d_3d_config_at_full_size(dev, full_vlm):
+    """BASELINE configs[2] (phase-vlm: one 2-D 448x448 and one 3-D 32x256x256 sample in the same batch, text lengths drawn from
+    128..512, sam = None): ragged ViT sequences (785 + 2 049 tokens) in one block-diagonal attention, two patch-embedding
+    geometries and two pooling shapes in one forward, right-padded decoder rows. Without the grounding heads the step is
+    bit-reproducible: replay and recompute-every-layer are checked to the last bit (norm / patch-embedding atomics excepted)."""
+    model, ddp, _ = full_vlm
+    batch = _batch_for(model, 'phase-vlm-mixed', dev)
+    vi = batch['vlm_inputs']
+    assert not bool(vi['attention_mask'].all()) and batch['image'][0].shape[1] == 1 and batch['image'][1].shape[1] == 32
+    keep_all = 200 << 30
+    l0, g0 = run_step(model, ddp, batch, 3, keep_all)
+    assert torch.isfinite(l0) and all(torch.isfinite(g).all() for g in g0.values()) and len(g0) > 1400
+    for what, budget in (('replay', keep_all), ('every layer recomputed', None)):
+        l, g = run_step(model, ddp, batch, 3, budget)
+        assert torch.equal(l, l0), what
+        diff = [n for n in g0 if not torch.equal(g[n], g0[n])]
+        atomics = ('norm', 'patch_embedding.')
+        assert all(any(a in n for a in atomics) for n in diff), (what, [n for n in diff if not any(a in n for a in atomics)][:5])
+        for n in diff:
+            assert rel(g[n], g0[n]) < 2e-3, (what, n)
+    with _without_dropout(model):
+        a, _ = run_step(model, ddp, batch, 3, keep_all)
+        perm = _permuted(batch)
+        b, _ = run_step(model, ddp, perm, 3, keep_all)
+    assert abs(a.item() - b.item()) / abs(a.item()) < 2e-3, (a.item(), b.item())
+
+
+def test_full_batch_of_eight_matches_four_pairs(dev, full_vlm):
+    """configs[1] at the benchmark's batch size (8 per GPU; the other tests of this file use 2): the weighted CE is a mean over the
+    valid target tokens, so the loss of the batch of eight equals the token-weighted mean of its four pairs (dropout off)."""
+    import bench
+    model, ddp, _ = full_vlm
+    big = bench.make_batch(bench.WORKLOADS['phase-vlm-448'], model._test_tok, 8, dev, seed=21)
+    with _without_dropout(model):
+        l8, _ = run_step(model, ddp, big, 5, 200 << 30)
+        num = den = 0.0
+        for i in range(0, 8, 2):
+            sub = {k: (v[i:i + 2] if isinstance(v, list) else v) for k, v in big.items()}
+            sub['vlm_inputs'] = {k: v[i:i + 2] for k, v in big['vlm_inputs'].items()}
+            sub['host'] = dict(input_ids=big['host']['input_ids'][i:i + 2], index_offsets=big['host']['index_offsets'][i:i + 2])
+            l2, _ = run_step(model, ddp, sub, 5, 200 << 30)
+            n = int((sub['vlm_inputs']['labels'] >= 0).sum())
+            num, den = num + l2.item() * n, den + n
+    assert abs(l8.item() - num / den) / abs(l8.item()) < 2e-3, (l8.item(), num / den)
 
 
 def test_full_size_step_properties(dev, full):
