@@ -526,8 +526,21 @@ def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlen
     return _SelfAttentionF32.apply(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
 
 
+_F32_HEAD_DIMS = (8, 16, 32, 48, 64, 96, 128)       # instantiations of attn_f32_*_k (csrc/attn_f32.hip)
+
+
 def attention_f32(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen=None):
     """dense batched [Bn, L, H*hd] or packed var-len [T, H*hd] (+cu_seqlens) fp32 attention"""
+    if head_dim not in _F32_HEAD_DIMS and head_dim < _F32_HEAD_DIMS[-1]:
+        # odd head widths (only tiny test models: the reference fixtures' SAM has 8 decoder heads over 32 / 16 channels): every head
+        # is zero-padded to the next width the kernels are instantiated for — scores and outputs are unchanged, `scale` stays that
+        # of the true width
+        hp = next(h for h in _F32_HEAD_DIMS if h >= head_dim)
+
+        def pad(t):
+            return torch.nn.functional.pad(t.reshape(*t.shape[:-1], n_heads, head_dim), (0, hp - head_dim)).reshape(*t.shape[:-1], n_heads * hp)
+        out = _AttentionF32.apply(pad(q), pad(k), pad(v), n_heads, hp, scale, cu_seqlens, max_seqlen)
+        return out.reshape(*out.shape[:-1], n_heads, hp)[..., :head_dim].reshape(*out.shape[:-1], n_heads * head_dim)
     return _AttentionF32.apply(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
 
 

@@ -525,6 +525,12 @@ def spec_tensor(name: str, shape, scale: float, dtype=torch.float32) -> torch.Te
     return ((2 * u - 1) * (scale * math.sqrt(3.0))).to(dtype).reshape(shape)
 
 
+def grad_rows(g: torch.Tensor) -> torch.Tensor:
+    """the part of a weight gradient a fixture keeps: the first 8 rows of a matrix, all of a vector"""
+    g = g.float()
+    return (g if g.ndim == 1 else g.reshape(g.shape[0], -1)[:8]).clone()
+
+
 def f2_true_width(R):
     """ONE decoder layer, ONE ViT layer at the true widths (h=4096 / i=11008 / 32 heads of 128; d=1792 / f=15360 / 16
     heads of 112) and the 768-wide two-way transformer block of SAM (F6), run by the reference in fp32 AND in bf16. Weights come from
@@ -576,7 +582,7 @@ def f2_true_width(R):
         (y.float() * gy).sum().backward()
         ps = dict(lay.named_parameters())
         return dict(y=y.detach().clone(), dx=torch.where(am.bool()[..., None], xx.grad, torch.zeros((), dtype=dtype)),
-                    wgrad_rows={n: ps[n].grad.float().reshape(ps[n].shape[0], -1)[:8].clone() for n in watch},
+                    wgrad_rows={n: grad_rows(ps[n].grad) for n in watch},
                     wgrad_norm={n: float(ps[n].grad.double().norm()) for n in watch})
     res['decoder_layer'] = dict(shape=(B, L, h), token_type_ids=tt, attention_mask=am, position_ids=pos, param_sums=sums,
                                 input_sums=dict(x=float(x.double().sum()), gy=float(gy.double().sum())),
@@ -607,7 +613,7 @@ def f2_true_width(R):
         (y.float() * gv).sum().backward()
         ps = dict(lay.named_parameters())
         return dict(y=y.detach()[0].clone(), dx=xx.grad[0].clone(),
-                    wgrad_rows={n: ps[n].grad.float().reshape(ps[n].shape[0], -1)[:8].clone() for n in vwatch},
+                    wgrad_rows={n: grad_rows(ps[n].grad) for n in vwatch},
                     wgrad_norm={n: float(ps[n].grad.double().norm()) for n in vwatch})
     res['vit_layer'] = dict(lens=lens, param_sums=vsums, input_sums=dict(x=float(xv.double().sum()), gy=float(gv.double().sum())),
                             fp32=run_vit(torch.float32))

@@ -680,20 +680,21 @@ def test_flat_adamw_param_groups_schedule_and_resume_match_torch(dev, K):
     opt2 = FlatAdamW(ddp2, lr=sched, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0)
     opt2.load_state_dict(sd)
     assert opt2.step_count == 8
-    rsd = ropt.state_dict()
+    import copy
+    rsd = copy.deepcopy(ropt.state_dict())           # (torch's load_state_dict aliases same-device state tensors: keep a private copy)
     opt3_params = [mk(s, nd) for s, nd in zip(shapes, nodecay)]
     with torch.no_grad():
         for a, b in zip(opt3_params, ref):
             a.copy_(b)
     ddp3 = BucketedGradAllReduce(opt3_params, world_size=1, bucket_bytes=16384)
     opt3 = FlatAdamW(ddp3, lr=sched, betas=(0.9, 0.95), weight_decay=0.1, max_grad_norm=1.0)
-    opt3.load_state_dict(rsd)                                            # a torch.optim.AdamW checkpoint loads too
+    opt3.load_state_dict(copy.deepcopy(rsd))                             # a torch.optim.AdamW checkpoint loads too
     mine_saved, ddp_saved = mine, ddp
     for trial_params, trial_ddp, trial_opt in ((mine2, ddp2, opt2), (opt3_params, ddp3, opt3)):
         ref_c = [torch.nn.Parameter(r.detach().clone()) for r in ref]
         ropt_c = torch.optim.AdamW([{'params': [r for r, nd in zip(ref_c, nodecay) if not nd], 'weight_decay': 0.1},
                                     {'params': [r for r, nd in zip(ref_c, nodecay) if nd], 'weight_decay': 0.0}], lr=2e-3, betas=(0.9, 0.95))
-        ropt_c.load_state_dict(rsd)
+        ropt_c.load_state_dict(copy.deepcopy(rsd))
         for it in range(8, 11):
             trial_ddp.zero_grad()
             g = torch.Generator(device=dev).manual_seed(100 + it)

@@ -32,6 +32,11 @@ TRUE_CFG = O.Cfg(vocab_size=32008, hidden_size=4096, intermediate_size=11008, nu
                  vision=O.VisionCfg(hidden_size=1792, num_heads=16, num_hidden_layers=1, intermediate_size=15360, layer_norm_eps=1e-6))
 
 
+def _rows(g):
+    g = g.float()
+    return g if g.ndim == 1 else g.reshape(g.shape[0], -1)[:8]
+
+
 def _leaf(t, dt, grad=True):
     return t.detach().to(dt).clone().requires_grad_(grad)
 
@@ -49,7 +54,7 @@ def run_decoder(f2, dt):
     xx = _leaf(x, dt)
     y = O.decoder_layer(sd, TRUE_CFG, 'l', xx, d['token_type_ids'], d['position_ids'], am.bool(), cos, sin)
     (y.float() * gy).sum().backward()
-    return dict(y=y, dx=xx.grad * am[..., None].to(dt), wgrad_rows={n: sd['l.' + n].grad.float().reshape(sd['l.' + n].shape[0], -1)[:8] for n in watch},
+    return dict(y=y, dx=xx.grad * am[..., None].to(dt), wgrad_rows={n: _rows(sd['l.' + n].grad) for n in watch},
                 wgrad_norm={n: float(sd['l.' + n].grad.double().norm()) for n in watch})
 
 
@@ -64,7 +69,7 @@ def run_vit(f2, dt):
     xx = _leaf(x, dt)
     y = O.vit_layer(sd, TRUE_CFG, 'l', xx, lens)
     (y.float() * gy).sum().backward()
-    return dict(y=y, dx=xx.grad, wgrad_rows={n: sd['l.' + n].grad.float().reshape(sd['l.' + n].shape[0], -1)[:8] for n in watch},
+    return dict(y=y, dx=xx.grad, wgrad_rows={n: _rows(sd['l.' + n].grad) for n in watch},
                 wgrad_norm={n: float(sd['l.' + n].grad.double().norm()) for n in watch})
 
 
