@@ -40,13 +40,39 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld_b
   }
 }
 
+// Split an fp32 fragment (8 consecutive k of one row, as two f32x4) into NS bf16 terms x = t0 + t1 (+ t2) + O(2^-8NS |x|):
+// t0 = bf16(x) (round to nearest even), t1 = bf16(x - t0), ... Each subtraction is exact in fp32.
+template <int NS>
+__device__ __forceinline__ void split_f32x8(const f32x4_t& lo4, const f32x4_t& hi4, bf16x8_t (&t)[NS]) {
+  float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    bf16x8_t h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)x[e];
+    t[s] = h;
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] -= (float)h[e];
+    }
+  }
+}
+
 // ESZ = 2: bf16 operands, v_mfma_f32_16x16x32_bf16, K-tile 64.
-// ESZ = 4: f32 operands, v_mfma_f32_16x16x4_f32 (exact f32 fma chain), K-tile 32. Same 128-byte LDS rows.
+// ESZ = 4: f32 operands, K-tile 32, same 128-byte LDS rows. NS = 0: v_mfma_f32_16x16x4_f32 (exact f32 fma chain, 1/16 of the bf16
+//   MFMA rate). NS = 2 / 3: "split-bf16" — every fp32 fragment is split IN REGISTERS into NS bf16 terms and the product is
+//   summed from the NS(NS+1)/2 leading cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: NS = 2 -> a0b0 + a0b1 + a1b0
+//   (3 MFMAs per K = 32 where the exact form needs 8 at 1/16 rate: 5.3x the matrix rate; products carry 16 mantissa bits, relative
+//   error ~2^-17 per term, sign-random, so a K-long dot product is good to ~1e-5 .. 1e-6 of its magnitude); NS = 3 -> 6 MFMAs,
+//   24 mantissa bits = fp32 products (2.7x). The fp32 fragment layout (lane (frow, fq) holds k = 8 fq .. 8 fq + 7) IS the bf16
+//   16x16x32 operand layout, so the split needs no data movement; its ~2.5 VALU instructions per element overlap with the MFMAs
+//   of the co-resident waves.
 // BMT = 128: 4 waves 2x2, wave tile 64 x 64.  BMT = 64 (fp32 output only): 4 waves 1x4, wave tile 64 rows x 32 columns —
 // twice the workgroups for the M ~ 3k fp32 linears of SAM / iSAM, whose 128-row grids (150 tiles) leave 40 % of the CUs idle.
-template <int ESZ, bool OUT_F32, int BMT = 128>
+template <int ESZ, bool OUT_F32, int BMT = 128, int NS = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   static_assert(BMT == 128 || (BMT == 64 && OUT_F32), "the 64-row tile has the direct fp32 epilogue only");
+  static_assert(NS == 0 || ESZ == 4, "the split applies to fp32 operands");
   constexpr int BKE = 128 / ESZ;  // K elements per tile
   constexpr int NI = BMT == 128 ? 4 : 2;                 // 16-wide n sub-tiles per wave
   constexpr int A_TILE = BMT * 128;                      // activation tile bytes
@@ -157,13 +183,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
         wb[i][0] = *reinterpret_cast<const f32x4_t*>(sb + i * 2048 + off_k0);
         wb[i][1] = *reinterpret_cast<const f32x4_t*>(sb + i * 2048 + off_k1);
       }
+      if constexpr (NS == 0) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s >> 2][s & 3], xa[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s >> 2][s & 3], xa[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
+      } else {
+        constexpr int NSS = NS > 0 ? NS : 1;
+        bf16x8_t xs[4][NSS], ws[NI][NSS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_f32x8<NSS>(xa[j][0], xa[j][1], xs[j]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) split_f32x8<NSS>(wb[i][0], wb[i][1], ws[i]);
+        // cross terms a_s b_t with s + t < NS, smallest first
+#pragma unroll
+        for (int d = NSS - 1; d >= 0; --d)
+#pragma unroll
+          for (int sw = 0; sw <= d; ++sw)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[i][sw], xs[j][d - sw], acc[i][j], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // next tile landed and everyone is done reading `buf`
@@ -380,6 +425,12 @@ static int big_tile_rows(int M, int N, int K, bool segmented) {
   return (forced != -192 && r192 * 78 < r256 * 100) ? 192 : 256;
 }
 
+// fp32 GEMM arithmetic: 0 = exact f32 MFMA, 2 = split-bf16 with 3 products (default), 3 = split-bf16 with 6 products.
+static int& f32_mode() {
+  static int mode = [] { const char* e = getenv("VM_F32_SPLIT"); const int v = e ? atoi(e) : 2; return (v == 0 || v == 2 || v == 3) ? v : 2; }();
+  return mode;
+}
+
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bke = 128 / esz, al = 16 / esz;
   if (!a || !a->A || !a->B || !a->C) return VM_ERR_BAD_ARG;
@@ -419,9 +470,17 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
     p.kchunk = per * bke;
     p.ksplit = (kt + per - 1) / per;
   }
-  // fp32 operands with fewer 128-row tiles than CUs: 64-row tiles (twice the workgroups)
-  const bool bm64 = esz == 4 && p.ksplit <= 1 && a->M > 64 &&
-                    (int64_t)((a->M + BM - 1) / BM + (segmented ? 1 : 0)) * ((a->N + BN - 1) / BN) < 256;
+  // fp32 operands: 128-row or 64-row tiles by rounds x cost. A CU holds 2 workgroups of the 128-row tile (198-241 VGPRs) and 3 of
+  // the 64-row tile (48 KiB of LDS each); a 64-row tile costs ~0.55 of a 128-row one (same weight tile, half the rows). The
+  // heads' shapes sit right at the quantisation edges: [3136 x 3072] is 600 tiles of 128 rows = 2 rounds over 512 slots (the second
+  // 17 % full) but 1176 tiles of 64 rows = 2 cheap rounds over 768 slots; [3136 x 768] fills 29 % of one round either way.
+  bool bm64 = false;
+  if (esz == 4 && p.ksplit <= 1 && a->M > 64) {
+    const int64_t tn = (a->N + BN - 1) / BN, sg = segmented ? 1 : 0;
+    const int64_t t128 = ((a->M + 127) / 128 + sg) * tn, t64 = ((a->M + 63) / 64 + sg) * tn;
+    const int64_t r128 = (t128 + 511) / 512, r64 = (t64 + 767) / 768;
+    bm64 = r64 * 55 < r128 * 100;
+  }
   const int bm = bm64 ? 64 : BM;
   p.tiles_m = (a->M + bm - 1) / bm + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
@@ -435,10 +494,20 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, stream);
     if (rc != VM_OK) return rc;
-  } else if (esz == 4 && bm64)
-    hipLaunchKernelGGL((gemm_nt_k<4, true, 64>), dim3(grid, 1), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
-  else if (esz == 4)
-    hipLaunchKernelGGL((gemm_nt_k<4, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  } else if (esz == 4 && bm64) {
+    const int lds = 2 * (64 * 128 + TILE_BYTES);
+    switch (f32_mode()) {
+      case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 0>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
+      case 3: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 3>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 2>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
+    }
+  } else if (esz == 4) {
+    switch (f32_mode()) {
+      case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 0>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
+      case 3: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 3>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 2>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
+    }
+  }
   else if (a->out_dtype == VM_F32)
     hipLaunchKernelGGL((gemm_nt_k<2, true>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p);
   else
@@ -451,5 +520,10 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
 int vm_gemm_bf16(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 2); }
 int vm_gemm_f32(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 4); }
+int vm_gemm_f32_mode(int mode) {
+  if (mode != 0 && mode != 2 && mode != 3) return VM_ERR_BAD_ARG;
+  f32_mode() = mode;
+  return VM_OK;
+}
 
 }  // extern "C"

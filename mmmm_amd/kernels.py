@@ -96,6 +96,12 @@ def gemm(
     return out
 
 
+def gemm_f32_mode(mode: int):
+    """arithmetic of vm_gemm_f32 (vm_gemm_f32_mode): 0 exact f32 MFMA, 2 split-bf16 in registers with 3 products (default), 3 with 6"""
+    hip.call('vm_gemm_f32_mode', mode)
+
+
+
 def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = None) -> torch.Tensor:
     """out[cols, rows_padded] = x^T, zero beyond the true row count (K-contiguous operand of a wgrad GEMM)"""
     assert x.dim() == 2 and x.stride(1) == 1

@@ -2,9 +2,12 @@
 same explicit weights and inputs.
 
 Tolerances (stated per BASELINE.json north_star: "logits within 1e-3 rel ... token-type indexing bit-exact"):
-  * bf16 path: the product rounds activations to bf16 where the reference's bf16-true path does; against the
-    fp32 oracle evaluated on the SAME bf16-rounded weights the relative L2 error of logits / hidden states is
-    bounded by 2e-2 (bf16 has 8 significant bits; 32+63 layers of rounding) and the scalar loss by 5e-3.
+  * bf16 path, evidence-based (same rule as tests/test_truewidth_gpu.py, where the yardstick is the REFERENCE's own bf16-true run):
+    the oracle is evaluated twice on the same bf16-rounded weights — in fp32 and in its bf16-true mode (pinned to the reference's
+    bf16 fixtures by tests/test_oracle_truewidth_cpu.py) — which gives the bf16 error of the reference arithmetic on THIS input,
+    e_or = |oracle_bf16 - oracle_fp32|. The HIP path must satisfy |hip - oracle_fp32| <= 1.3 e_or and |hip - oracle_bf16| <= 1.5 e_or
+    (`bf16_ok`). The coarse absolute bounds of round 1 (2e-2 on logits / hidden states, 5e-3 on the loss, 6e-2 on gradients) stay
+    as a backstop. 1e-3 is not reachable by any bf16-true evaluation, the reference's included (e_or is 5e-3 .. 1.5e-2 here).
   * integer routing (expert masks, row maps) is bit-exact.
 """
 import pytest
@@ -44,17 +47,23 @@ def lm(dev):
     return m
 
 
-def run_oracle(m, batch, need_grad=False):
+def run_oracle(m, batch, need_grad=False, dtype=torch.float32):
+    """dtype fp32: the exact result on the model's (bf16-rounded) weights; bf16: the oracle's bf16-true mode"""
     from oracle import vividmed as O
-    sd = oracle_state(m)
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in oracle_state(m).items()}
     if need_grad:
         sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     vi = cpu(batch['vlm_inputs'])
-    out = O.causal_lm_forward(sd, oracle_cfg(m.config), vi['input_ids'], image=[x.float() for x in cpu(batch['image'])],
+    out = O.causal_lm_forward(sd, oracle_cfg(m.config), vi['input_ids'], image=[x.to(dtype) for x in cpu(batch['image'])],
                               patch_size=batch['patch_size'], pool_size=batch['pool_size'], token_type_ids=vi['token_type_ids'],
                               attention_mask=vi['attention_mask'], position_ids=vi['position_ids'], labels=vi['labels'],
-                              weight=vi['weight'], rope_dtype=torch.bfloat16)
+                              weight=vi['weight'].to(dtype), rope_dtype=torch.bfloat16)
     return out, sd
+
+
+def bf16_ok(what, hip, or16, or32, a=1.3, b=1.5, floor=1e-4):
+    e_or, e_hip, d = rel(or16.float(), or32), rel(hip.float(), or32), rel(hip.float(), or16.float())
+    assert e_hip <= a * e_or + floor and d <= b * e_or + floor, (what, dict(e_oracle_bf16=e_or, e_hip=e_hip, hip_vs_oracle_bf16=d))
 
 
 def test_routing_is_bit_exact(dev, lm):
@@ -79,12 +88,17 @@ def test_lm_forward_matches_oracle(dev, lm):
         out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'],
                  output_hidden_states=True, materialize_logits=True)
     ref, _ = run_oracle(lm, batch)
+    with torch.no_grad():
+        ref16, _ = run_oracle(lm, batch, dtype=torch.bfloat16)
     am = cpu(batch['vlm_inputs']['attention_mask']).bool()
     assert abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()) < 5e-3, (out.loss.item(), ref.loss.item())
     assert rel(out.logits.cpu()[am], ref.logits[am]) < 2e-2
+    bf16_ok('logits', out.logits.cpu()[am], ref16.logits[am], ref.logits[am])
     assert len(out.hidden_states) == len(ref.hidden_states)
     for i in range(len(ref.hidden_states)):
         assert rel(out.hidden_states[i].float().cpu()[am], ref.hidden_states[i][am]) < 2e-2, i
+        if i:
+            bf16_ok(f'hidden {i}', out.hidden_states[i].float().cpu()[am], ref16.hidden_states[i][am], ref.hidden_states[i][am])
 
 
 def test_vision_tower_matches_oracle(dev, lm):
@@ -110,6 +124,8 @@ def test_lm_backward_matches_oracle(dev, lm):
     out.loss.backward()
     ref, sd = run_oracle(lm, batch, need_grad=True)
     ref.loss.backward()
+    ref16, sd16 = run_oracle(lm, batch, need_grad=True, dtype=torch.bfloat16)
+    ref16.loss.backward()
     assert abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()) < 5e-3
     checked = 0
     worst = {}
@@ -123,6 +139,7 @@ def test_lm_backward_matches_oracle(dev, lm):
             continue
         e = rel(p.grad.float(), g_ref)
         worst[name] = e
+        bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 1.4, 1.6)
         checked += 1
     bad = {k: v for k, v in worst.items() if v > 6e-2}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

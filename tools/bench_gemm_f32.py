@@ -17,8 +17,9 @@ for M, N, Kd in [(3136, 768, 3072), (3136, 3072, 768), (3136, 768, 768), (768, 7
     a = torch.randn(M, Kd, device=dev); w = torch.randn(N, Kd, device=dev) / 32
     out = torch.zeros(M, N, device=dev)
     ref = a.double() @ w.double().T
-    for ks in (1, 2, 3, 4, 8):
+    for mode, ks in ((0, 1), (2, 1), (3, 1), (2, 4)):
+        K.gemm_f32_mode(mode)
         out.zero_(); gemm_raw(a, w, out, ks)
         err = ((out.double() - ref).norm() / ref.norm()).item()
         ms = timeit(lambda: gemm_raw(a, w, out, ks), iters=20)
-        print(f'M={M} N={N} K={Kd} ksplit={ks}: {ms*1e3:.0f} us {2*M*N*Kd/ms/1e9:.0f} TF err {err:.1e}', flush=True)
+        print(f'M={M} N={N} K={Kd} mode={mode} ksplit={ks}: {ms*1e3:.0f} us {2*M*N*Kd/ms/1e9:.0f} TF err {err:.1e}', flush=True)
