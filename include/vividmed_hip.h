@@ -268,6 +268,12 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
  * tiles_per_entry = grid.x (entries with more 64x64 tiles loop). n <= 65535. */
 int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, int dtype, void* stream);
 
+/* Table of fp32 side accumulators folded into bf16 gradient slots in ONE launch: desc_dev holds n records of three int64
+ * {dst bf16*, src float*, count}; dst[j] = bf16(dst[j] + bf16(src[j])) (the rounding of AccumulateGrad's `grad += g.to(bf16)`), then
+ * src[j] = 0. The column-sum gradients of the bf16 norm layers (RMSNorm modeling_cogvlm.py:30-41, LayerNorm visual.py:129-141) are
+ * accumulated atomically in fp32 by vm_rmsnorm_bwd / vm_layernorm_bwd; this moves all of a gradient bucket's at once. n <= 65535. */
+int vm_accum_f32_table(const int64_t* desc_dev, int n, int blocks_per_entry, void* stream);
+
 /* same, restricted to one row segment of the token-routed layout:
  * segment 0 = rows [0, counts[0]), segment 1 = rows [counts[0], counts[1]) (device counts);
  * out[c, i] = in[begin + i, c], zero beyond the segment. Feeds the per-expert LoRA weight gradients. */

@@ -449,6 +449,23 @@ __global__ __launch_bounds__(256) void transpose_batched_k(const int64_t* __rest
   }
 }
 
+
+// ---------------------------------------------------------------- fp32 side accumulators -> bf16 gradient slots
+// desc[i] = {dst (bf16*), src (float*), count}: dst[j] = bf16(float(dst[j]) + float(bf16(src[j]))), src[j] = 0 — the rounding of
+// AccumulateGrad's `grad += g.to(bf16)`. One launch per gradient bucket moves every column-sum gradient of the norm layers
+// (atomically accumulated in fp32 by norm_bwd_dwdb_k) into its bf16 slot and leaves the accumulator zeroed for the next step.
+__global__ __launch_bounds__(256) void accum_f32_table_k(const int64_t* __restrict__ desc) {
+  const int64_t* d = desc + (int64_t)blockIdx.y * 3;
+  unsigned short* dst = reinterpret_cast<unsigned short*>(d[0]);
+  float* src = reinterpret_cast<float*>(d[1]);
+  const int n = (int)d[2];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float g = bf2f(f2bf(src[i]));
+    dst[i] = f2bf(bf2f(dst[i]) + g);
+    src[i] = 0.f;
+  }
+}
+
 // ---------------------------------------------------------------- fused gradient clip + AdamW over a flat bucket
 // One pass over a flat parameter / gradient / moment bucket (torch.optim.AdamW semantics, decoupled weight decay, maths in
 // fp32, states stored in the parameter dtype): g' = g * clip_coef[0] (device scalar: no host round trip for the norm),
@@ -780,6 +797,14 @@ int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, in
   if (!desc_dev || tiles_per_entry <= 0 || n > 65535) return VM_ERR_BAD_ARG;
   dim3 grid(tiles_per_entry, n);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_batched_k<T>, grid, dim3(256), 0, (hipStream_t)stream, desc_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_accum_f32_table(const int64_t* desc_dev, int n, int blocks_per_entry, void* stream) {
+  if (n <= 0) return VM_OK;
+  if (!desc_dev || blocks_per_entry <= 0 || n > 65535) return VM_ERR_BAD_ARG;
+  hipLaunchKernelGGL(accum_f32_table_k, dim3(blocks_per_entry, n), dim3(256), 0, (hipStream_t)stream, desc_dev);
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

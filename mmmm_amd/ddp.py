@@ -57,6 +57,10 @@ class BucketedGradAllReduce:
         self._ready: set[int] = set()             # ids of the parameters whose slot is final in this step
         self._step_streams: set = set()           # every stream that produced or joined gradients in this step (finish() joins them)
         self._build(bucket_bytes)
+        self._f32_acc: dict[int, torch.Tensor] = {}                  # id(param) -> fp32 side accumulator (f32_accumulator)
+        self._f32_chunks: list = []                                   # [(buffer, used)] the accumulators are carved from
+        self._f32_entries: dict[int, list] = {}                       # bucket index -> [(dst ptr, src ptr, count)]
+        self._f32_tables: dict[int, torch.Tensor] = {}                # bucket index -> device table (rebuilt when entries are added)
         self._hooks = []
         self._acc_nodes = []                      # the hooks live on the AccumulateGrad nodes: keep the nodes alive
         for p in self.params:
@@ -66,6 +70,8 @@ class BucketedGradAllReduce:
             self._hooks.append(acc.register_prehook(lambda grads, p=p: self._mark_ready(p) if grads[0] is None else None))
             self._hooks.append(p.register_post_accumulate_grad_hook(self._mark_ready))
             p._vm_grad_ready = self._note_stream
+            if p.dtype == torch.bfloat16 and p.is_cuda:
+                p._vm_f32_acc = self.f32_accumulator
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):
@@ -101,6 +107,38 @@ class BucketedGradAllReduce:
     def total_bytes(self) -> int:
         return sum(b.buffer.numel() * b.buffer.element_size() for b in self.buckets)
 
+    # -- fp32 side accumulators for bf16 slots ---------------------------------------------------
+    def f32_accumulator(self, p: torch.Tensor) -> torch.Tensor:
+        """A zeroed fp32 vector of p.numel() elements that kernels may accumulate into atomically during backward (the column-sum
+        gradients of the bf16 norm layers). When p's bucket is launched, ONE kernel per bucket rounds every such accumulator into
+        its bf16 gradient slot — `grad += acc.to(bf16)`, AccumulateGrad's rounding — and zeroes it again. Replaces, per norm
+        parameter and step, a zeros() + a cast + an add launch."""
+        acc = self._f32_acc.get(id(p))
+        if acc is None:
+            n = (p.numel() + 3) // 4 * 4
+            if not self._f32_chunks or self._f32_chunks[-1][1] + n > self._f32_chunks[-1][0].numel():
+                self._f32_chunks.append([torch.zeros(max(1 << 20, n), dtype=torch.float32, device=p.device), 0])
+            buf, used = self._f32_chunks[-1]
+            acc = buf[used:used + p.numel()]
+            self._f32_chunks[-1][1] = used + n
+            self._f32_acc[id(p)] = acc
+            bi = self._bucket_of[id(p)]
+            self._f32_entries.setdefault(bi, []).append((p.grad.data_ptr(), acc.data_ptr(), p.numel(), p))
+            self._f32_tables.pop(bi, None)
+        return acc
+
+    def _fold_f32(self, bi: int):
+        ent = self._f32_entries.get(bi)
+        if not ent:
+            return
+        from . import kernels as K
+        t = self._f32_tables.get(bi)
+        if t is None or any(e[0] != e[3].grad.data_ptr() for e in ent):      # (grad views re-pointed: rebuild)
+            ent[:] = [(e[3].grad.data_ptr(), e[1], e[2], e[3]) for e in ent]
+            rows = torch.tensor([[e[0], e[1], e[2]] for e in ent], dtype=torch.int64)
+            t = self._f32_tables[bi] = rows.pin_memory().to(self.buckets[bi].buffer.device, non_blocking=True)
+        K.accum_f32_table(t, len(ent))
+
     # -- backward hooks -------------------------------------------------------------------------
     def _note_stream(self, p: torch.Tensor):
         """a fused kernel accumulated into p.grad on the current stream (possibly one of several uses of p in this step)"""
@@ -130,6 +168,7 @@ class BucketedGradAllReduce:
                     cur.wait_stream(st)
             b.streams.clear()
             self._step_streams.add(cur)
+            self._fold_f32(self.buckets.index(b))
         if self.collectives:
             # SUM now, divide once after the collective (finish): dividing a bf16 bucket before the sum would round every
             # rank's contribution separately (the reference's DDP averages after the reduction as well)
@@ -206,5 +245,7 @@ class BucketedGradAllReduce:
         for p in self.params:
             if getattr(p, '_vm_grad_ready', None) is not None:
                 del p._vm_grad_ready
+            if getattr(p, '_vm_f32_acc', None) is not None:
+                del p._vm_f32_acc
         for h in self._hooks:
             h.remove()

@@ -309,6 +309,10 @@ def _norm_params_off_path(params, run_kernel, keep_alive):
     def run():
         if all(p.grad.dtype == torch.float32 for p in ps):
             run_kernel(*[p.grad for p in ps])
+        elif all(getattr(p, '_vm_f32_acc', None) is not None for p in ps):
+            # bf16 slots: the kernel's atomics land in fp32 side accumulators that the bucket folds into the slots with one
+            # launch when it is reduced (ddp.f32_accumulator) — no zeros(), cast and add per parameter
+            run_kernel(*[p._vm_f32_acc(p) for p in ps])
         else:
             outs = run_kernel(*[None for _ in ps])
             for p, g in zip(ps, outs):

@@ -120,6 +120,12 @@ def transpose_batched(desc: torch.Tensor, n: int, tiles_per_entry: int, dtype: t
     hip.call('vm_transpose_batched', ptr(desc), n, tiles_per_entry, dtype_code(dtype), stream())
 
 
+def accum_f32_table(desc: torch.Tensor, n: int, blocks_per_entry: int = 4):
+    """desc: int64 [n, 3] on the device — {dst bf16 ptr, src fp32 ptr, count}: dst += bf16(src), src = 0, one launch"""
+    assert desc.dtype == torch.int64 and desc.is_contiguous() and desc.numel() >= n * 3
+    hip.call('vm_accum_f32_table', ptr(desc), n, blocks_per_entry, stream())
+
+
 def transpose_segment(x: torch.Tensor, counts: torch.Tensor, segment: int, pad_to: int = 64) -> torch.Tensor:
     """transpose of row segment `segment` (0: [0,counts[0]), 1: [counts[0],counts[1])) -> [cols, rows_padded]"""
     rows, cols = x.shape
