@@ -156,14 +156,16 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
 
 /* fp32 GEMM for the fp32 islands `sam`, `isam_model`, `vg_proj` (mmmm/models/mmmm.py:137-138): every nn.Linear of
  * segvol/modeling/{image_encoder,transformer,mask_decoder}.py and their weight gradients. Same NT form and argument struct (all
- * dtypes f32; K % 32 == 0, K2 % 32 == 0, ld % 4 == 0). Arithmetic (vm_gemm_f32_mode; default 2, or VM_F32_SPLIT in the environment
+ * dtypes f32; K % 32 == 0, K2 % 32 == 0, ld % 4 == 0). Arithmetic (vm_gemm_f32_mode; default 3, or VM_F32_SPLIT in the environment
  * of the first call):
  *   0  v_mfma_f32_16x16x4_f32, the exact f32 fma chain (1/16 of the bf16 matrix rate);
  *   2  split-bf16: a = a0 + a1, b = b0 + b1 with bf16 terms split in registers, a.b ~ a0 b0 + a0 b1 + a1 b0 on
  *      v_mfma_f32_16x16x32_bf16 with fp32 accumulation — products carry 16 mantissa bits. Measured (tools/bench_gemm_f32.py,
  *      tools/f32_mode_accuracy.py): 1.6-2.3x faster than mode 0 on the heads' shapes, 3e-6 relative error per product matrix,
- *      1.2e-5 end to end through SAM-B (mode 0: 1.3e-6) against the 1e-4 tolerance of the fp32 islands;
- *   3  three terms, six products: 24 mantissa bits, i.e. fp32 products (error as mode 0; 1.2-1.4x faster). */
+ *      1.2e-5 end to end on SAM-B's masks (mode 0: 1.3e-6) but up to 9e-4 on the prompt gradients through iSAM — outside the 1e-4
+ *      bar of the fp32 islands, hence opt-in;
+ *   3  (default) three terms, six products: 24 mantissa bits, i.e. fp32 products — error as mode 0 (4e-7 per product matrix,
+ *      1.3e-6 end to end), 1.2-1.4x faster than mode 0. */
 int vm_gemm_f32(const vm_gemm_args* args_host, void* stream);
 int vm_gemm_f32_mode(int mode);
 

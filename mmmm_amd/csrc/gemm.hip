@@ -425,9 +425,9 @@ static int big_tile_rows(int M, int N, int K, bool segmented) {
   return (forced != -192 && r192 * 78 < r256 * 100) ? 192 : 256;
 }
 
-// fp32 GEMM arithmetic: 0 = exact f32 MFMA, 2 = split-bf16 with 3 products (default), 3 = split-bf16 with 6 products.
+// fp32 GEMM arithmetic: 0 = exact f32 MFMA, 2 = split-bf16 with 3 products, 3 = split-bf16 with 6 products (default: fp32 products).
 static int& f32_mode() {
-  static int mode = [] { const char* e = getenv("VM_F32_SPLIT"); const int v = e ? atoi(e) : 2; return (v == 0 || v == 2 || v == 3) ? v : 2; }();
+  static int mode = [] { const char* e = getenv("VM_F32_SPLIT"); const int v = e ? atoi(e) : 3; return (v == 0 || v == 2 || v == 3) ? v : 3; }();
   return mode;
 }
 
@@ -498,14 +498,14 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
     switch (f32_mode()) {
       case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 0>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
-      case 3: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 3>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
-      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 2>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
+      case 2: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 2>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 3>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
     }
   } else if (esz == 4) {
     switch (f32_mode()) {
       case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 0>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
-      case 3: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 3>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
-      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 2>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
+      case 2: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 2>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 3>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
     }
   }
   else if (a->out_dtype == VM_F32)

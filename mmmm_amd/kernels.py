@@ -97,7 +97,7 @@ def gemm(
 
 
 def gemm_f32_mode(mode: int):
-    """arithmetic of vm_gemm_f32 (vm_gemm_f32_mode): 0 exact f32 MFMA, 2 split-bf16 in registers with 3 products (default), 3 with 6"""
+    """arithmetic of vm_gemm_f32 (vm_gemm_f32_mode): 0 exact f32 MFMA, 2 split-bf16 in registers with 3 products, 3 with 6 (default)"""
     hip.call('vm_gemm_f32_mode', mode)
 
 

@@ -139,15 +139,15 @@ def test_gemm_f32(dev, K, M, N, K_):
     w = torch.randn(N, K_, device=dev) / math.sqrt(K_)
     bias = torch.randn(N, device=dev)
     ref = (a.double() @ w.double().T + bias.double()).float()
-    # arithmetic modes of vm_gemm_f32: exact f32 MFMA, split-bf16 with 3 products (16-bit products; the default of the fp32 islands),
-    # split-bf16 with 6 products (fp32 products)
+    # arithmetic modes of vm_gemm_f32: exact f32 MFMA, split-bf16 with 6 products (fp32 products; the default of the fp32 islands),
+    # split-bf16 with 3 products (16-bit products, opt-in)
     try:
         for mode, tol in ((0, 2e-6), (3, 2e-6), (2, 1.5e-5)):
             K.gemm_f32_mode(mode)
             out = K.gemm(a, w, bias=bias)
             assert rel_err(out, ref) < tol, (mode, rel_err(out, ref))
     finally:
-        K.gemm_f32_mode(2)
+        K.gemm_f32_mode(3)
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])

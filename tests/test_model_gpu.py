@@ -139,7 +139,9 @@ def test_lm_backward_matches_oracle(dev, lm):
             continue
         e = rel(p.grad.float(), g_ref)
         worst[name] = e
-        bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 1.4, 1.6)
+        # (a vector summed from a handful of bf16 rows — cls / boi / eoi embeddings — has no averaging: wider factor)
+        few = p.numel() <= 2 * lm.config.hidden_size
+        bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 2.5 if few else 1.4, 2.5 if few else 1.6)
         checked += 1
     bad = {k: v for k, v in worst.items() if v > 6e-2}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

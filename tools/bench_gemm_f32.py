@@ -23,3 +23,4 @@ for M, N, Kd in [(3136, 768, 3072), (3136, 3072, 768), (3136, 768, 768), (768, 7
         err = ((out.double() - ref).norm() / ref.norm()).item()
         ms = timeit(lambda: gemm_raw(a, w, out, ks), iters=20)
         print(f'M={M} N={N} K={Kd} mode={mode} ksplit={ks}: {ms*1e3:.0f} us {2*M*N*Kd/ms/1e9:.0f} TF err {err:.1e}', flush=True)
+K.gemm_f32_mode(3)

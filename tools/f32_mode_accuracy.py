@@ -51,4 +51,4 @@ def full(mode, ref_cache={}):
 
 for mode in (0, 3, 2):
     print('mode', mode, 'tiny SAM masks / prompt grads', tiny(mode), 'SAM-B 3-D masks / prompt grads', full(mode), flush=True)
-K.gemm_f32_mode(2)
+K.gemm_f32_mode(3)
