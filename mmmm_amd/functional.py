@@ -20,10 +20,15 @@ from . import kernels as K
 _CU_CACHE: dict = {}
 
 
+_UPLOAD_STREAMS: dict = {}
+
+
 def cu_seqlens_tensor(lens, device) -> torch.Tensor:
-    """int32 prefix sums of `lens` on `device`, cached per (lens, device); a miss goes through pinned memory and a non-blocking
-    copy (a fresh torch.tensor(..., device=...) is a blocking pageable host->device copy, i.e. a full host/GPU synchronisation
-    in the middle of the forward pass)"""
+    """int32 prefix sums of `lens` on `device`, cached per (lens, device). A miss uploads through pinned memory on a dedicated
+    copy stream and waits for THAT copy only: a fresh torch.tensor(..., device=...) is a blocking pageable host->device copy queued
+    behind everything on the current stream, i.e. a full host/GPU synchronisation in the middle of the forward pass; a non-blocking
+    copy on the current stream would be invisible to the OTHER streams that read the cached table (the two grounding heads run on two
+    streams: the first step after a miss read a half-written table, found by the full-size replay tests)."""
     key = (tuple(int(n) for n in lens), str(device))
     t = _CU_CACHE.get(key)
     if t is None:
@@ -31,12 +36,20 @@ def cu_seqlens_tensor(lens, device) -> torch.Tensor:
         for n in key[0]:
             cu.append(cu[-1] + n)
         if len(_CU_CACHE) > 256:
+            if torch.device(device).type == 'cuda':
+                torch.cuda.synchronize(device)          # kernels in flight may still read the tables about to be freed
             _CU_CACHE.clear()
         host = torch.tensor(cu, dtype=torch.int32)
-        if torch.device(device).type == 'cuda':      # pinned + non-blocking: a new length tuple (variable text lengths) must not
-            t = host.pin_memory().to(device, non_blocking=True)       # stall the host in the middle of the forward
+        dev = torch.device(device)
+        if dev.type == 'cuda':
+            st = _UPLOAD_STREAMS.get(dev)
+            if st is None:
+                st = _UPLOAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                t = host.pin_memory().to(dev, non_blocking=True)
+            st.synchronize()                            # the table is resident before any stream can be handed it
         else:
-            t = host.to(device)
+            t = host.to(dev)
         _CU_CACHE[key] = t
     return t
 
@@ -669,6 +682,51 @@ class _DiceFocal(Function):
 def dice_focal(x, target, gamma: float, alpha: float | None):
     """x fp32 [R, n] logits, target uint8 [R, n] | None -> (dice [R], focal_sum [R])"""
     return _DiceFocal.apply(x, target, gamma, alpha)
+
+
+# ----------------------------------------------------------------------------- hyper-network mask product (SAM mask decoder)
+class _HyperProduct(Function):
+    """y[p] = up[p] @ w[p]^T for every prompt p: up [P, V, C] fp32 (up-scaled image embedding per prompt, channel-last), w [P, M, C]
+    (per-prompt hyper-network weights) -> y [P, V, M]. Reference mask_decoder.py:139-147 (`einsum('n m c, n c ... -> n m ...')`).
+    One autograd node for all prompts: the per-prompt GEMMs write into slices of ONE output / gradient buffer, so no prompt-wise
+    indexing reaches autograd (whose slice backward zero-fills and adds a full `up`-sized tensor per prompt: 16 x 77 MB per head and
+    step at 448 x 448)."""
+    @staticmethod
+    def forward(ctx, up, w):
+        P, V, C = up.shape
+        M = w.shape[1]
+        Mp = (M + 3) // 4 * 4
+        y = torch.empty(P, V, Mp, dtype=up.dtype, device=up.device)
+        upp, wp = _padk(up.reshape(P * V, C), w.reshape(P * M, C))
+        upp, wp = upp.view(P, V, -1), wp.view(P, M, -1)
+        for n in range(P):
+            K.gemm(upp[n], wp[n], out=y[n][:, :M])
+        ctx.save_for_backward(up, w)
+        return y[..., :M]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        up, w = ctx.saved_tensors
+        P, V, C = up.shape
+        M = w.shape[1]
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        d_up = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_up = torch.empty_like(up)
+            wt = w.transpose(1, 2).contiguous()                    # [P, C, M]: tiny
+            for n in range(P):
+                dyp, wtp = _padk(dy[n], wt[n])
+                K.gemm(dyp, wtp, out=d_up[n])
+        if ctx.needs_input_grad[1]:
+            d_w = torch.zeros_like(w)              # (tiny; the split-K product of a V-long contraction accumulates into it)
+            for n in range(P):
+                K.gemm(K.transpose(dy[n], pad_to=64), K.transpose(up[n], pad_to=64), out=d_w[n], out_is_zero=True)
+        return d_up, d_w
+
+
+def hyper_product(up, w):
+    return _HyperProduct.apply(up, w)
 
 
 # ----------------------------------------------------------------------------- weighted CE over the vocabulary

@@ -35,7 +35,7 @@ def gemm(
     out: torch.Tensor | None = None, out_dtype: torch.dtype | None = None,
     act: int = hip.ACT_NONE,
     counts: torch.Tensor | None = None, split: int = -1,
-    drop_p: float = 0.0, drop_seed: int = 0,
+    drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False,
 ) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
 
@@ -53,7 +53,10 @@ def gemm(
     # all of K alone, so K is split over workgroups that accumulate into a zeroed fp32 C
     ksplit = 0
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if (out is None and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
+    if out is not None:
+        out_dtype = out.dtype
+    # (`out_is_zero`: the caller passes a ZEROED fp32 `out`, which the split-K form may accumulate into)
+    if ((out is None or out_is_zero) and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
             and tiles <= 48 and K >= 1024):
         # a handful of output tiles with a long contraction (weight gradients of the fp32 grounding heads). Only for small
         # outputs: the fp32 atomic epilogue runs at ~60 G atomics/s and already costs more than it saves at 150 tiles.

@@ -1,7 +1,7 @@
 """SAM / SegVol mask decoder (reference segvol/modeling/mask_decoder.py) in channel-last layout on the fp32 HIP
 kernels: the two ConvTranspose3d(k=2,s=2) upscalers are GEMMs + a pixel-shuffle view, the channel LayerNorm is the
 row-wise LN kernel, and the hyper-network product `einsum('n m c, n c ... -> n m ...')` plus the text-similarity term
-is ONE GEMM per prompt against [hyper_in ; txt_align(text)]."""
+is ONE GEMM per prompt against hyper_in + txt_align(text) (functional.hyper_product: one autograd node for all prompts)."""
 from __future__ import annotations
 
 import torch
@@ -103,9 +103,6 @@ class MaskDecoder(nn.Module):
         txt = self.txt_align_upscaled_embedding(text_embedding)                                      # [P, C/8]
         Dp, Hp, Wp, c8 = up.shape[1:]
         M = self.num_mask_tokens
-        masks = []
-        for n in range(P):
-            w_n = torch.cat([hyper[n], txt[n:n + 1]], dim=0)                                          # [M+1, C/8]
-            y = Fh.linear(up[n].reshape(-1, c8), w_n)                                                 # [voxels, M+1]
-            masks.append((y[:, :M] + y[:, M:M + 1]).t().reshape(M, Dp, Hp, Wp))
-        return torch.stack(masks, dim=0), mask_tokens_out
+        # masks[p, m] = up[p] . hyper[p, m] + up[p] . txt[p] = up[p] . (hyper[p, m] + txt[p]): one product per prompt against M rows
+        y = Fh.hyper_product(up.reshape(P, -1, c8), hyper + txt[:, None])                            # [P, voxels, M]
+        return y.transpose(1, 2).reshape(P, M, Dp, Hp, Wp), mask_tokens_out
