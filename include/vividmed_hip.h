@@ -154,6 +154,19 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
                     int out_dtype, int M, const int32_t* counts_dev, int segment, const int32_t* nrows_dev, int splits,
                     float alpha, float drop_p, uint64_t drop_seed, int drop_cols, void* stream);
 
+/* fp8 path of BASELINE configs[4] ("model-hr ... fp8 MFMA path"; shapes conf/model-hr.yaml:5-18). The reference has no fp8 arithmetic:
+ * this is the build's own reduced-precision mode for the FROZEN base-weight linears of the two bf16 towers (visual.py:93,100,120-122,
+ * modeling_cogvlm.py:54-56,243-245,277-279), forward and input gradient; LoRA factors, norms, attention, the heads stay as they are.
+ * vm_quant_rows_fp8: x8[r][c] = e4m3(x[r][c] 448 / amax_r) (OCP e4m3fn), scale[r] = amax_r / 448, inv_scale[r] = 1 / scale[r] (optional).
+ *   cols % 16 == 0, ld8 % 16 == 0; rows >= nrows_dev[0] are written as zeros with unit scale.
+ * vm_gemm_fp8: the NT form of vm_gemm_bf16 with A [M, K], B / B_1 [N, K] holding e4m3 bytes (lda / ldb in bytes, K % 128 == 0) on
+ *   v_mfma_f32_16x16x128_f8f6f4 (twice the bf16 matrix rate), fp32 accumulation:
+ *     C = act(row_scale[m] col_scale[n] sum_k A8 B8 + alpha2 (A2 B2^T, dropout-masked) + bias) + residual.
+ *   The bf16 extension operands must be pre-divided: A2[m][:] / row_scale[m], B2[n][:] / col_scale[n] (B2_1 by col_scale_1). */
+int vm_quant_rows_fp8(const void* x, int64_t ldx, void* x8, int64_t ld8, float* scale, float* inv_scale, int rows, int cols, int dtype,
+                      const int32_t* nrows_dev, void* stream);
+int vm_gemm_fp8(const vm_gemm_args* args_host, const float* row_scale, const float* col_scale, const float* col_scale_1, void* stream);
+
 /* fp32 GEMM for the fp32 islands `sam`, `isam_model`, `vg_proj` (mmmm/models/mmmm.py:137-138): every nn.Linear of
  * segvol/modeling/{image_encoder,transformer,mask_decoder}.py and their weight gradients. Same NT form and argument struct (all
  * dtypes f32; K % 32 == 0, K2 % 32 == 0, ld % 4 == 0). Arithmetic (vm_gemm_f32_mode; default 3, or VM_F32_SPLIT in the environment

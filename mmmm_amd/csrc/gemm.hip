@@ -397,7 +397,7 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
   return VM_OK;
 }
 
-extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, void* stream);
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, void* stream);
 
 // Tile choice by estimated rounds over the 256 CUs. Measured on MI355X (tools/bench_gemm_vit.py): one round of 256x256
 // tiles (1 workgroup per CU) costs about 3.0x one round-equivalent of 128x128 tiles (2 co-resident workgroups per CU
@@ -463,6 +463,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   p.act = a->act;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
   p.ksplit = 1; p.kchunk = a->K;
+  p.row_scale = nullptr; p.col_scale0 = p.col_scale1 = nullptr;
   if (a->ksplit > 1) {
     if (a->out_dtype != VM_F32 || a->act != VM_ACT_NONE || a->K2 != 0) return VM_ERR_BAD_ARG;
     const int kt = a->K / bke;
@@ -492,7 +493,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   vm_prof_begin_(kind, stream, &tok);
   const int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
   if (big) {
-    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, stream);
+    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 0, stream);
     if (rc != VM_OK) return rc;
   } else if (esz == 4 && bm64) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
@@ -523,6 +524,51 @@ int vm_gemm_f32(const vm_gemm_args* a, void* stream) { return gemm_launch(a, str
 int vm_gemm_f32_mode(int mode) {
   if (mode != 0 && mode != 2 && mode != 3) return VM_ERR_BAD_ARG;
   f32_mode() = mode;
+  return VM_OK;
+}
+
+/* fp8 (OCP e4m3) main product on v_mfma_f32_16x16x128_f8f6f4 with per-row / per-output-channel scales, LoRA extension in bf16:
+ *   C[m][n] = act( sa[m] sb[n] sum_k A8[m][k] B8[n][k]  +  alpha2 mask sum_r A2[m][r] B2[n][r]  + bias ) + residual
+ * The extension operands must arrive PRE-DIVIDED by the same scales (A2[m][:] / sa[m], B2[n][:] / sb[n]): the kernel accumulates the
+ * extension first, then the raw fp8 products, and multiplies the sum by sa[m] sb[n] once. */
+int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_scale, const float* col_scale_1, void* stream) {
+  if (!a || !a->A || !a->B || !a->C || !row_scale || !col_scale) return VM_ERR_BAD_ARG;
+  if (a->M <= 0 || a->N <= 0) return VM_OK;
+  if (a->K <= 0 || a->K % 128 || a->K2 % 64 || a->K2 < 0) return VM_ERR_BAD_ARG;
+  if (a->lda % 16 || a->ldb % 16) return VM_ERR_BAD_ARG;                      /* bytes = elements for fp8 */
+  if (a->K2 > 0 && (!a->A2 || !a->B2 || a->lda2 % 8 || a->ldb2 % 8)) return VM_ERR_BAD_ARG;
+  if (a->out_dtype != VM_BF16 && a->out_dtype != VM_F32) return VM_ERR_BAD_ARG;
+  if (a->ldc % 4 || a->ksplit > 1) return VM_ERR_BAD_ARG;
+  if (a->drop_p > 0.f && (a->N % 4)) return VM_ERR_BAD_ARG;
+  const bool segmented = a->counts_dev != nullptr || a->split >= 0;
+  if (segmented && (!a->B_1 || !col_scale_1)) return VM_ERR_BAD_ARG;
+  if ((int64_t)256 * a->lda + a->K >= (1ll << 31) || (int64_t)256 * a->ldb + a->K >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
+  GemmParams p;
+  p.A = (const char*)a->A; p.lda = a->lda / 2;                                /* the kernel turns element counts into bytes with x 2 */
+  p.B0 = (const char*)a->B; p.B1 = (const char*)(a->B_1 ? a->B_1 : a->B); p.ldb = a->ldb / 2;
+  p.A2 = (const char*)a->A2; p.lda2 = a->lda2;
+  p.B2_0 = (const char*)a->B2; p.B2_1 = (const char*)(a->B2_1 ? a->B2_1 : a->B2); p.ldb2 = a->ldb2;
+  p.K2 = a->K2; p.alpha2 = a->alpha2;
+  p.bias0 = a->bias; p.bias1 = a->bias_1 ? a->bias_1 : a->bias;
+  p.residual = a->residual; p.ldr = a->ldr;
+  p.C = a->C; p.ldc = a->ldc;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.counts_dev = a->counts_dev;
+  p.split = segmented ? (a->counts_dev ? 0 : a->split) : -1;
+  p.act = a->act;
+  p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
+  p.ksplit = 1; p.kchunk = a->K;
+  p.row_scale = row_scale; p.col_scale0 = col_scale; p.col_scale1 = col_scale_1 ? col_scale_1 : col_scale;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+  int big = big_tile_rows(a->M, a->N, a->K / 2 + a->K2, segmented);          /* rounds x cost in bf16-equivalent K-tiles */
+  if (!big) big = 256;                                                        /* the fp8 main loop exists in the 256-column kernel only */
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_GEMM_BF16, stream, &tok);
+  const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 1, stream);
+  if (rc != VM_OK) return rc;
+  vm_prof_end2_(VM_PROF_GEMM_BF16, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2),
+                ((double)a->M + (double)a->N) * (a->K + 2.0 * a->K2) + (double)a->M * a->N * (a->out_dtype == VM_F32 ? 4 : 2));
+  VM_LAUNCH_CHECK();
   return VM_OK;
 }
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
 // structure, 12 instead of 16 MFMAs per phase). The 192-row tile exists for tile-count quantisation: [6280 x 1792] is 175
 // tiles of 256 rows (68 % of one round over 256 CUs) but 231 tiles of 192 rows, [6280 x 5376] is 525 (3 rounds) vs 693
 // (3 rounds of 0.75 the work).
-template <bool OUT_F32, int MI>
+template <bool OUT_F32, int MI, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   constexpr int BMT = 64 * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -145,7 +145,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
   const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
   const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
-  const int kt_ext = p.K2 / 64, kt_main = p.K / 64, kt_total = kt_ext + kt_main;
+  // F8: the main operands are e4m3 bytes — a 128-byte LDS row holds 128 k instead of 64, everything else (DMA, swizzle, phases) is
+  // unchanged; the LoRA extension tiles stay bf16
+  const int kt_ext = p.K2 / 64, kt_main = F8 ? p.K / 128 : p.K / 64, kt_total = kt_ext + kt_main;
   __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
   int lda2_b = 0, ldb2_b = 0;
   if (kt_ext > 0) {
@@ -192,14 +194,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
       bF[nh][j][1] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k1);
     }
   };
-  auto mma = [&](int mh, int nh) {
+  auto mma = [&](int mh, int nh, auto f8_tag) {
+    if constexpr (decltype(f8_tag)::value) {
+      // one v_mfma_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales) per accumulator tile and K-tile: twice the bf16 matrix rate.
+      // A lane's two 16-byte fragment halves are the k-chunks fq and fq + 4 of the row — not 32 consecutive k, but the weight and the
+      // activation operand use the SAME k permutation, so the sum over k is complete.
+      typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int i = 0; i < MI; ++i) {
+        const i32x4_t a0 = __builtin_bit_cast(i32x4_t, aF[i][0]), a1 = __builtin_bit_cast(i32x4_t, aF[i][1]);
+        const i32x8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < 2; ++j) {
+          const i32x4_t b0 = __builtin_bit_cast(i32x4_t, bF[nh][j][0]), b1 = __builtin_bit_cast(i32x4_t, bF[nh][j][1]);
+          const i32x8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          acc[mh * MI + i][nh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[mh * MI + i][nh * 2 + j], 0, 0, 0, 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[mh * MI + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[nh][j][ks], aF[i][ks], acc[mh * MI + i][nh * 2 + j], 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[mh * MI + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bF[nh][j][ks], aF[i][ks], acc[mh * MI + i][nh * 2 + j], 0, 0, 0);
+    }
   };
 
   // Wave rows are STAGGERED by one barrier interval: the two waves that share a SIMD (wave w and w+4, i.e. wm = 0
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   // EVERY wave's R segment is sufficient for both rows (row 0 merely retires one interval early) and keeps the steady
   // state free of wave-dependent branches. The loop is peeled (HN = "a next K-tile exists") so it has no data-dependent
   // branches between MFMA clusters either.
-  auto ktile = [&](int t, auto hn_tag) {
+  auto ktile = [&](int t, auto hn_tag, auto f8_tag) {
     constexpr bool HN = decltype(hn_tag)::value;
     const char* st = smem + (t & 1) * STAGE_BYTES2;
     // ---- phase 1: quadrant (0,0); needs A-h0, B-h0; issues A-h0'; retires B-h1 of this tile
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(0, 0);
+    mma(0, 0, f8_tag);
     __builtin_amdgcn_sched_barrier(0);
     POST_MMA_BARRIER();
     // ---- phase 2: quadrant (0,1); needs B-h1; issues B-h0'; retires A-h1 of this tile
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(0, 1);
+    mma(0, 1, f8_tag);
     __builtin_amdgcn_sched_barrier(0);
     POST_MMA_BARRIER();
     // ---- phase 3: quadrant (1,1); needs A-h1; issues B-h1'
@@ -237,14 +257,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     if (HN) stage(t + 1, 3);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(1, 1);
+    mma(1, 1, f8_tag);
     __builtin_amdgcn_sched_barrier(0);
     POST_MMA_BARRIER();
     // ---- phase 4: quadrant (1,0); B-h0 fragments are still in registers; issues A-h1'; retires A-h0', B-h0'
     if (HN) { stage(t + 1, 1); VM_WAIT_VMCNT(4); }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    mma(1, 0);
+    mma(1, 0, f8_tag);
     __builtin_amdgcn_sched_barrier(0);
     POST_MMA_BARRIER();
   };
@@ -274,43 +294,65 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   // extension tiles (LoRA rank slab; the main K always follows), the scale between the two loops — never inside one:
   // with the scale in the loop body the compiler hoists the 128 loop-invariant mask hashes and spills them
   int t = 0;
+  const std::integral_constant<bool, F8> main_kind{};
   if (kt_ext > 0) {
-    for (; t < kt_ext; ++t) ktile(t, std::true_type{});
+    for (; t < kt_ext; ++t) ktile(t, std::true_type{}, std::false_type{});
     ext_scale();
   }
-  for (; t + 1 < kt_total; ++t) ktile(t, std::true_type{});
-  ktile(kt_total - 1, std::false_type{});
+  for (; t + 1 < kt_total; ++t) ktile(t, std::true_type{}, main_kind);
+  ktile(kt_total - 1, std::false_type{}, main_kind);
 #ifndef VM_G256_NO_STAGGER
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #endif
 
+  if constexpr (F8) {
+    // dequantise: acc[m][n] *= row_scale[m] * col_scale[n] (the extension operands were pre-divided by the same scales on the host)
+    const float* cs = seg ? p.col_scale1 : p.col_scale0;
+    f32x4_t cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[j][r] = (n + r < p.N) ? cs[n + r] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int ml = wm * 32 * MI + i * 16 + frow;
+      const float rs = ml < nrows ? p.row_scale[row0 + ml] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= cv[j] * rs;
+    }
+  }
   epilogue256<OUT_F32, MI>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
 }
 
 }  // namespace
 
-// called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles
-extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, void* stream) {
+// called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles; f8 != 0: e4m3 main operands (vm_gemm_fp8)
+extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, void* stream) {
   GemmParams p = *(const GemmParams*)params;
   if (tile_rows != 256 && tile_rows != 192) return VM_ERR_BAD_ARG;
   p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
   p.tiles_n = (p.N + 255) / 256;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[4] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
-                          (const void*)gemm256_k<true, 3>};
+    const void* fns[8] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+                          (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
+                          (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
     attr_set = true;
   }
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (tile_rows == 256) {
-    if (out_f32) hipLaunchKernelGGL((gemm256_k<true, 4>), grid, block, LDS_BYTES2, st, p);
-    else hipLaunchKernelGGL((gemm256_k<false, 4>), grid, block, LDS_BYTES2, st, p);
+#define VM_G256_LAUNCH(O, M_, F_) hipLaunchKernelGGL((gemm256_k<O, M_, F_>), grid, block, LDS_BYTES2, st, p)
+  if (f8) {
+    if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
+    else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
   } else {
-    if (out_f32) hipLaunchKernelGGL((gemm256_k<true, 3>), grid, block, LDS_BYTES2, st, p);
-    else hipLaunchKernelGGL((gemm256_k<false, 3>), grid, block, LDS_BYTES2, st, p);
+    if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, false); else VM_G256_LAUNCH(false, 4, false); }
+    else { if (out_f32) VM_G256_LAUNCH(true, 3, false); else VM_G256_LAUNCH(false, 3, false); }
   }
+#undef VM_G256_LAUNCH
   return VM_OK;
 }

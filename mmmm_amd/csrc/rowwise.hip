@@ -450,6 +450,49 @@ __global__ __launch_bounds__(256) void transpose_batched_k(const int64_t* __rest
 }
 
 
+// ---------------------------------------------------------------- per-row fp8 (OCP e4m3) quantisation
+// x8[r][c] = e4m3(x[r][c] * 448 / amax_r), scale[r] = amax_r / 448 (1 for an all-zero row), inv_scale[r] = 1 / scale[r]: the operands of
+// vm_gemm_fp8 (activations per token row; frozen weights per output channel, once). One wave per row, two passes over the row
+// (the second one hits L2), 16 elements per lane and step.
+template <typename T>
+__global__ __launch_bounds__(ROW_THREADS) void quant_rows_fp8_k(const T* __restrict__ x, int64_t ldx, unsigned char* __restrict__ x8, int64_t ld8,
+                                                                float* __restrict__ scale, float* __restrict__ inv_scale, int rows, int cols,
+                                                                const int32_t* nrows_dev) {
+  int rows_true = rows;
+  if (nrows_dev) rows_true = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  unsigned char* o = x8 + (int64_t)row * ld8;
+  if (row >= rows_true) {           // rows beyond the device-side count: zeros, unit scale
+    for (int c = lane * 16; c < cols; c += 64 * 16) *reinterpret_cast<i32x4_t*>(o + c) = (i32x4_t){0, 0, 0, 0};
+    if (lane == 0) { scale[row] = 1.f; if (inv_scale) inv_scale[row] = 1.f; }
+    return;
+  }
+  float amax = 0.f;
+  for (int c = lane * 16; c < cols; c += 64 * 16) {
+#pragma unroll
+    for (int h = 0; h < 16; ++h) amax = fmaxf(amax, fabsf(Elem<T>::ld(xr[c + h])));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.f;
+  const float inv = amax > 0.f ? 448.0f / amax : 1.f;
+  if (lane == 0) { scale[row] = sc; if (inv_scale) inv_scale[row] = 1.0f / sc; }
+  for (int c = lane * 16; c < cols; c += 64 * 16) {
+    i32x4_t pk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float f0 = Elem<T>::ld(xr[c + 4 * q]) * inv, f1 = Elem<T>::ld(xr[c + 4 * q + 1]) * inv;
+      const float f2 = Elem<T>::ld(xr[c + 4 * q + 2]) * inv, f3 = Elem<T>::ld(xr[c + 4 * q + 3]) * inv;
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, w, true);
+      pk[q] = w;
+    }
+    *reinterpret_cast<i32x4_t*>(o + c) = pk;
+  }
+}
+
 // ---------------------------------------------------------------- fp32 side accumulators -> bf16 gradient slots
 // desc[i] = {dst (bf16*), src (float*), count}: dst[j] = bf16(float(dst[j]) + float(bf16(src[j]))), src[j] = 0 — the rounding of
 // AccumulateGrad's `grad += g.to(bf16)`. One launch per gradient bucket moves every column-sum gradient of the norm layers
@@ -797,6 +840,17 @@ int vm_transpose_batched(const int64_t* desc_dev, int n, int tiles_per_entry, in
   if (!desc_dev || tiles_per_entry <= 0 || n > 65535) return VM_ERR_BAD_ARG;
   dim3 grid(tiles_per_entry, n);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_batched_k<T>, grid, dim3(256), 0, (hipStream_t)stream, desc_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_quant_rows_fp8(const void* x, int64_t ldx, void* x8, int64_t ld8, float* scale, float* inv_scale, int rows, int cols, int dtype,
+                      const int32_t* nrows_dev, void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  if (!x || !x8 || !scale || cols % 16 || ld8 % 16 || ldx % 8 || !aligned16(x) || !aligned16(x8)) return VM_ERR_BAD_ARG;
+  dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(quant_rows_fp8_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, ldx,
+                                           (unsigned char*)x8, ld8, scale, inv_scale, rows, cols, nrows_dev));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

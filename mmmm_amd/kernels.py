@@ -99,6 +99,58 @@ def gemm(
     return out
 
 
+def quant_rows_fp8(x: torch.Tensor, nrows: torch.Tensor | None = None, need_inv: bool = True):
+    """per-row e4m3 quantisation: -> (x8 uint8 [R, C], scale fp32 [R], inv_scale fp32 [R] | None)"""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 16 == 0
+    R, Cc = x.shape
+    x8 = torch.empty(R, Cc, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(R, dtype=torch.float32, device=x.device)
+    inv = torch.empty(R, dtype=torch.float32, device=x.device) if need_inv else None
+    hip.call('vm_quant_rows_fp8', ptr(x), x.stride(0), ptr(x8), x8.stride(0), ptr(scale), ptr(inv), R, Cc, dtype_code(x.dtype), ptr(nrows), stream())
+    return x8, scale, inv
+
+
+def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, *, w1_8: torch.Tensor | None = None,
+             sw1: torch.Tensor | None = None, a2: torch.Tensor | None = None, b2: torch.Tensor | None = None, b2_1: torch.Tensor | None = None,
+             alpha2: float = 1.0, bias: torch.Tensor | None = None, bias1: torch.Tensor | None = None, residual: torch.Tensor | None = None,
+             out_dtype: torch.dtype = torch.bfloat16, counts: torch.Tensor | None = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+    """out[M, N] = sa[m] sw[n] (a8 @ w8^T) + alpha2 (a2 @ b2^T) + bias (+ residual) with e4m3 a8 / w8 (vm_gemm_fp8). a2 / b2 must already
+    be divided by sa / sw (functional._Linear does that)."""
+    M, Kd = a8.shape
+    N = w8.shape[0]
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and w8.shape[1] == Kd and Kd % 128 == 0
+    assert sa.dtype == torch.float32 and sa.numel() == M and sw.dtype == torch.float32 and sw.numel() == N
+    al = 8 if out_dtype == torch.bfloat16 else 4
+    Np = (N + al - 1) // al * al
+    out = torch.empty(M, Np, dtype=out_dtype, device=a8.device)
+    if Np != N:
+        out = out[:, :N]
+    g = hip.GemmArgs()
+    g.A, g.lda = ptr(a8), a8.stride(0)
+    g.B, g.B_1, g.ldb = ptr(w8), ptr(w1_8), w8.stride(0)
+    if a2 is not None:
+        assert b2 is not None and a2.shape[0] == M and b2.shape == (N, a2.shape[1]) and a2.dtype == torch.bfloat16
+        g.A2, g.lda2 = ptr(a2), _ld(a2)
+        g.B2, g.B2_1, g.ldb2 = ptr(b2), ptr(b2_1), _ld(b2)
+        g.K2 = a2.shape[1]
+    else:
+        g.K2 = 0
+    g.alpha2 = alpha2
+    g.bias, g.bias_1 = ptr(bias), ptr(bias1)
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape == out.shape
+        g.residual, g.ldr = ptr(residual), _ld(residual)
+    g.C, g.ldc = ptr(out), _ld(out)
+    g.M, g.N, g.K = M, N, Kd
+    g.counts_dev = ptr(counts)
+    g.split, g.act = -1, hip.ACT_NONE
+    g.out_dtype = dtype_code(out.dtype)
+    g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF
+    g.alpha, g.ksplit = 1.0, 0
+    hip.call('vm_gemm_fp8', C.addressof(g), ptr(sa), ptr(sw), ptr(sw1), stream())
+    return out
+
+
 def gemm_f32_mode(mode: int):
     """arithmetic of vm_gemm_f32 (vm_gemm_f32_mode): 0 exact f32 MFMA, 2 split-bf16 in registers with 3 products, 3 with 6 (default)"""
     hip.call('vm_gemm_f32_mode', mode)
