@@ -328,6 +328,9 @@ def main():
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': fused clip + AdamW kernel over the gradient buckets; 'torch': clip on the buckets + torch.optim.AdamW(fused)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fp8', action='store_true',
+                    help="BASELINE configs[4] 'fp8 MFMA path': frozen base-weight linears of the ViT-E / decoder in e4m3 (forward + input gradient); "
+                         'everything else as in the bf16 run. Not valid for the bf16 headline workload.')
     ap.add_argument('--batches', type=int, default=4, help='distinct synthetic batches (seeded per rank) rotated through the timed region')
     ap.add_argument('--dry-run-cpu', action='store_true',
                     help='launcher / collective plumbing check without a GPU: gloo backend, a toy CPU network through the same '
@@ -364,6 +367,10 @@ def main():
     from mmmm_amd.ddp import BucketedGradAllReduce
     w = WORKLOADS[args.workload]
     model, tok = build(w, device, args.depth_scale)
+    n_fp8 = 0
+    if args.fp8:
+        from mmmm_amd.models.lora import enable_fp8
+        n_fp8 = enable_fp8(model)
     trainable = [p for p in model.parameters() if p.requires_grad]
     ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist)
     from mmmm_amd.optim import FlatAdamW
@@ -463,10 +470,10 @@ def main():
         out = {
             'metric': 'train images/sec/node', 'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'fp8-e4m3 frozen-weight GEMMs (fwd + dgrad), bf16 elsewhere' if args.fp8 else 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
             # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
@@ -474,6 +481,7 @@ def main():
                          | {'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 2**30, 1)},
             'model_tflops_per_image': fl_sample / 1e12,
             'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,
+            'mfma_utilisation_note': 'algorithmic training FLOPs / dense bf16 peak (2.5 PFLOP/s)' + ('; the e4m3 GEMMs of this run have a 5 PFLOP/s peak' if args.fp8 else ''),
         }
         if use_events:
             ms, fl, n = K.prof_collect(hip.PROF_GEMM_BF16)

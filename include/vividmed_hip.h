@@ -166,6 +166,8 @@ int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ld
 int vm_quant_rows_fp8(const void* x, int64_t ldx, void* x8, int64_t ld8, float* scale, float* inv_scale, int rows, int cols, int dtype,
                       const int32_t* nrows_dev, void* stream);
 int vm_gemm_fp8(const vm_gemm_args* args_host, const float* row_scale, const float* col_scale, const float* col_scale_1, void* stream);
+/* out[r][c] = bf16(x[r][c] * s[r]): the pre-division of the extension operands (s = inv_scale of vm_quant_rows_fp8). cols % 8 == 0. */
+int vm_scale_rows_bf16(const void* x, int64_t ldx, const float* s, void* out, int64_t ldo, int rows, int cols, void* stream);
 
 /* fp32 GEMM for the fp32 islands `sam`, `isam_model`, `vg_proj` (mmmm/models/mmmm.py:137-138): every nn.Linear of
  * segvol/modeling/{image_encoder,transformer,mask_decoder}.py and their weight gradients. Same NT form and argument struct (all

@@ -493,6 +493,21 @@ __global__ __launch_bounds__(ROW_THREADS) void quant_rows_fp8_k(const T* __restr
   }
 }
 
+// out[r][c] = x[r][c] * s[r] (bf16 in / out, fp32 factor): pre-division of the LoRA extension operands of vm_gemm_fp8 by the fp8 scales
+__global__ __launch_bounds__(256) void scale_rows_bf16_k(const unsigned short* __restrict__ x, int64_t ldx, const float* __restrict__ s,
+                                                         unsigned short* __restrict__ out, int64_t ldo, int rows, int cols) {
+  const int groups = cols / 8;
+  const int64_t total = (int64_t)rows * groups;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / groups), c = (int)(i % groups) * 8;
+    const float f = s[r];
+    u16x8_t v = *reinterpret_cast<const u16x8_t*>(x + (int64_t)r * ldx + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * f);
+    *reinterpret_cast<u16x8_t*>(out + (int64_t)r * ldo + c) = v;
+  }
+}
+
 // ---------------------------------------------------------------- fp32 side accumulators -> bf16 gradient slots
 // desc[i] = {dst (bf16*), src (float*), count}: dst[j] = bf16(float(dst[j]) + float(bf16(src[j]))), src[j] = 0 — the rounding of
 // AccumulateGrad's `grad += g.to(bf16)`. One launch per gradient bucket moves every column-sum gradient of the norm layers
@@ -851,6 +866,16 @@ int vm_quant_rows_fp8(const void* x, int64_t ldx, void* x8, int64_t ld8, float* 
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(quant_rows_fp8_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, ldx,
                                            (unsigned char*)x8, ld8, scale, inv_scale, rows, cols, nrows_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_scale_rows_bf16(const void* x, int64_t ldx, const float* s, void* out, int64_t ldo, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  if (!x || !s || !out || cols % 8 || ldx % 8 || ldo % 8 || !aligned16(x) || !aligned16(out)) return VM_ERR_BAD_ARG;
+  const int64_t total = (int64_t)rows * (cols / 8);
+  hipLaunchKernelGGL(scale_rows_bf16_k, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, ldx, s, (unsigned short*)out, ldo, rows, cols);
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

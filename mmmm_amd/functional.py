@@ -69,6 +69,9 @@ class LinearMeta:
     Bt0: torch.Tensor | None = None
     At1: torch.Tensor | None = None
     Bt1: torch.Tensor | None = None
+    # fp8 mode of the frozen base weight (models/lora.py Fp8Weights per expert): e4m3 copies of W and W^T with their scales
+    f8_0: object = None
+    f8_1: object = None
 
 
 def _t(w: torch.Tensor) -> torch.Tensor:
@@ -199,13 +202,25 @@ class _Linear(Function):
         t = None
         if lora:
             t = _lora_project(x, A0, A1, meta.gated, counts, meta.drop_p, meta.drop_seed)
-        xp, W0p, W1p = _padk(x, W0, W1)
-        y = K.gemm(
-            xp, W0p, w1=W1p if meta.gated else None,
-            a2=t, b2=B0 if lora else None, b2_1=B1 if (lora and meta.gated) else None, alpha2=meta.lora_scale if lora else 1.0,
-            bias=b0, bias1=b1 if meta.gated else None, residual=residual,
-            counts=counts if meta.gated else None, act=meta.act, out_dtype=meta.out_dtype,
-        )
+        if meta.f8_0 is not None and meta.act == hip.ACT_NONE:
+            # frozen base weight in e4m3 (BASELINE configs[4]): quantise the activation rows, main product on the fp8 MFMA, the LoRA
+            # extension in bf16 with its operands pre-divided by the scales the epilogue multiplies back
+            f0, f1 = meta.f8_0, meta.f8_1
+            x8, sx, inv_x = K.quant_rows_fp8(x, counts[1:2] if meta.gated else None)
+            y = K.gemm_fp8(
+                x8, sx, f0.w8, f0.sw, w1_8=f1.w8 if meta.gated else None, sw1=f1.sw if meta.gated else None,
+                a2=K.scale_rows(t, inv_x) if lora else None, b2=K.scale_rows(B0, f0.inv_sw) if lora else None,
+                b2_1=K.scale_rows(B1, f1.inv_sw) if (lora and meta.gated) else None, alpha2=meta.lora_scale if lora else 1.0,
+                bias=b0, bias1=b1 if meta.gated else None, residual=residual, counts=counts if meta.gated else None,
+                out_dtype=meta.out_dtype or x.dtype)
+        else:
+            xp, W0p, W1p = _padk(x, W0, W1)
+            y = K.gemm(
+                xp, W0p, w1=W1p if meta.gated else None,
+                a2=t, b2=B0 if lora else None, b2_1=B1 if (lora and meta.gated) else None, alpha2=meta.lora_scale if lora else 1.0,
+                bias=b0, bias1=b1 if meta.gated else None, residual=residual,
+                counts=counts if meta.gated else None, act=meta.act, out_dtype=meta.out_dtype,
+            )
         ctx.meta, ctx.lora = meta, lora
         ctx.save_for_backward(x, t, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
         ctx.has_residual = residual is not None
@@ -229,7 +244,17 @@ class _Linear(Function):
             Bt0 = meta.Bt0 if meta.Bt0 is not None else _t(B0)
             Bt1 = (meta.Bt1 if meta.Bt1 is not None else _t(B1)) if gated else None
             u = _lora_project(dy, Bt0, Bt1, gated, counts)                                # [M, r] = dy · B
-        if need[1]:
+        if need[1] and meta.f8_0 is not None:
+            # fp8 dgrad: dy rows quantised per token, W^T in e4m3 per input channel
+            f0, f1 = meta.f8_0, meta.f8_1
+            dy8, sdy, inv_dy = K.quant_rows_fp8(dy, counts[1:2] if gated else None)
+            At0 = (meta.At0 if meta.At0 is not None else _t(A0)) if lora else None
+            At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
+            g[1] = K.gemm_fp8(dy8, sdy, f0.wt8, f0.swt, w1_8=f1.wt8 if gated else None, sw1=f1.swt if gated else None,
+                              a2=K.scale_rows(u, inv_dy) if lora else None, b2=K.scale_rows(At0, f0.inv_swt) if lora else None,
+                              b2_1=K.scale_rows(At1, f1.inv_swt) if (lora and gated) else None, alpha2=s if lora else 1.0, counts=cnt,
+                              drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed, out_dtype=x.dtype)
+        elif need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None
             dyp, wt0, wt1 = _padk(dy, wt0, wt1)

@@ -110,6 +110,14 @@ def quant_rows_fp8(x: torch.Tensor, nrows: torch.Tensor | None = None, need_inv:
     return x8, scale, inv
 
 
+def scale_rows(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """bf16 [R, C] times an fp32 factor per row -> bf16"""
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and s.dtype == torch.float32 and s.numel() >= x.shape[0]
+    out = torch.empty_like(x)
+    hip.call('vm_scale_rows_bf16', ptr(x), x.stride(0), ptr(s), ptr(out), out.stride(0), x.shape[0], x.shape[1], stream())
+    return out
+
+
 def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, *, w1_8: torch.Tensor | None = None,
              sw1: torch.Tensor | None = None, a2: torch.Tensor | None = None, b2: torch.Tensor | None = None, b2_1: torch.Tensor | None = None,
              alpha2: float = 1.0, bias: torch.Tensor | None = None, bias1: torch.Tensor | None = None, residual: torch.Tensor | None = None,

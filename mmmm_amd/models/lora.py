@@ -93,6 +93,19 @@ class ActivationBudget:
         return n
 
 
+class Fp8Weights:
+    """e4m3 copies of one FROZEN weight for the fp8 mode (BASELINE configs[4]): `w8` [out, in] with one scale per output channel for the
+    forward, `wt8` [in, out] with one scale per input channel for the input gradient. 2 bytes per parameter in total — what the bf16
+    transposed copy alone costs, which this mode no longer keeps."""
+
+    def __init__(self, weight: torch.Tensor):
+        w = weight.detach()
+        self.w8, self.sw, self.inv_sw = K.quant_rows_fp8(w)
+        wt = K.transpose(w)
+        self.wt8, self.swt, self.inv_swt = K.quant_rows_fp8(wt)
+        del wt
+
+
 class Linear(nn.Module):
     """y = x W^T (+ b) (+ s·B A drop(x)); frozen weights keep a transposed copy for the dgrad GEMM."""
 
@@ -106,6 +119,7 @@ class Linear(nn.Module):
         self.lora_cfg: LoraConfig | None = None
         self._wt: torch.Tensor | None = None
         self._lora_t: tuple | None = None      # (At [in, r], Bt [r, out], version key) — see LoraTransposes
+        self.f8: Fp8Weights | None = None      # set by enable_fp8(): e4m3 copies of the frozen weight
         self._site = StepState.new_site()
         nn.init.normal_(self.weight, std=0.02)
 
@@ -130,9 +144,13 @@ class Linear(nn.Module):
     def B(self):
         return self.lora_B['default'].weight if self.lora_B is not None else None
 
+    def fp8_eligible(self) -> bool:
+        w = self.weight
+        return (not w.requires_grad and w.dtype == torch.bfloat16 and w.is_cuda and self.in_features % 128 == 0 and self.out_features % 128 == 0)
+
     def wt(self) -> torch.Tensor | None:
         """transposed copy [in, out] of a FROZEN weight (kept resident: 288 GB HBM buys a plain NT dgrad)"""
-        if self.weight.requires_grad:
+        if self.weight.requires_grad or self.f8 is not None:
             return None
         if self._wt is None or self._wt.device != self.weight.device or self._wt.dtype != self.weight.dtype:
             self._wt = K.transpose(self.weight.detach())
@@ -148,6 +166,7 @@ class Linear(nn.Module):
 
     def meta(self, gated: bool = False) -> Fh.LinearMeta:
         m = Fh.LinearMeta(gated=gated)
+        m.f8_0 = self.f8
         if self.lora_cfg is not None:
             m.lora_scale = self.lora_cfg.scale
             if torch.is_grad_enabled():
@@ -192,6 +211,9 @@ def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torc
     lora_l = language.lora_cfg is not None
     if lora_l and torch.is_grad_enabled():
         m.At1, m.Bt1 = language.lora_t()
+    m.f8_1 = language.f8
+    if (m.f8_0 is None) != (m.f8_1 is None):
+        m.f8_0 = m.f8_1 = None
     return Fh.linear(
         x, vision.weight, meta=m, Wt0=vision.wt() if need_dx else None, b0=vision.bias, A0=vision.A, B0=vision.B,
         W1=language.weight, Wt1=language.wt() if need_dx else None, b1=language.bias,
@@ -250,3 +272,16 @@ class LoraTransposes:
             K.transpose_batched(self.desc[i:i + n].contiguous() if i else self.desc, n, self.tiles, self.dtype)
         for m, (At, Bt) in zip(self.linears, self.bufs):
             m._lora_t = (At, Bt, (m.A._version, m.B._version, m.A.data_ptr(), m.B.data_ptr(), ParamGeneration.value))
+
+
+@torch.no_grad()
+def enable_fp8(root: nn.Module) -> int:
+    """Switch every eligible frozen bf16 Linear below `root` to the fp8 mode (e4m3 main product, forward and input gradient; see
+    functional._Linear): quantise W and W^T once and drop the resident bf16 transpose. Returns the number of linears converted."""
+    n = 0
+    for m in root.modules():
+        if isinstance(m, Linear) and m.f8 is None and m.fp8_eligible():
+            m.f8 = Fp8Weights(m.weight)
+            m._wt = None
+            n += 1
+    return n
