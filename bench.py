@@ -411,6 +411,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             budget = int(t.item())
         ActivationBudget.limit = max(budget, 0)
+        if rank == 0:
+            print(f'[plan] peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GB, reserved {r0 / 2**30:.1f} GB with every layer recomputed -> activation budget {budget / 2**30:.1f} GB', file=sys.stderr)
         # calibration (untimed): the per-layer estimate of ActivationBudget.claim covers the two big transformers, not the
         # grounding heads' fp32 volumes, the allocator's fragmentation or the frees deferred by the side streams. If a step
         # under the plan reserves more than --hbm-fraction of the HBM (the pool still grows ~10 % over the following steps before it settles) the caching allocator ends up flushing and re-allocating its pool
@@ -428,6 +430,8 @@ def main():
                 t = torch.tensor([r1], device=device, dtype=torch.int64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 r1 = int(t.item())
+            if rank == 0:
+                print(f'[calibrate] budget {ActivationBudget.limit / 2**30:.1f} GB kept {ActivationBudget.last_plan}: reserved {r1 / 2**30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB (target {target / 2**30:.0f} GB)', file=sys.stderr)
             if r1 <= target + (4 << 30) or ActivationBudget.limit == 0:
                 break
             # reserved memory is ~linear in the kept bytes: interpolate between "nothing kept" (r0) and this plan (r1)

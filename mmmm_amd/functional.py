@@ -105,6 +105,8 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
 
 
 _WGRAD_STREAMS: dict = {}
+_WGRAD_EVENTS: dict = {}
+SIDE_LAG = int(os.environ.get('VM_SIDE_LAG', '24'))          # forked calls the side stream may trail the main stream by (~2 transformer layers)
 _HELD: list = []              # tensors kept referenced until the running backward pass ends (_hold_until_backward_ends)
 
 
@@ -148,6 +150,17 @@ def _off_critical_path(fn, device, keep_alive):
     for t in keep_alive:
         if t is not None:
             t.record_stream(side)
+    # Bound how far the side stream may fall behind. Every tensor recorded on it (whole activation / gradient matrices) is withheld
+    # from the caching allocator until the side stream has passed this point, and a side stream that runs "in the shadows" of the
+    # dgrad GEMMs can lag by dozens of layers: the allocator then grows its pool instead of recycling — 170 GB allocated but
+    # 200-260 GB reserved on the high-resolution workloads, different from run to run. The main stream therefore waits for the work
+    # forked SIDE_LAG calls ago (normally long finished: no stall), which caps the withheld memory at a few layers' worth.
+    ring = _WGRAD_EVENTS.setdefault(device, [])
+    ev = torch.cuda.Event()
+    ev.record(side)
+    ring.append(ev)
+    if len(ring) > SIDE_LAG:
+        cur.wait_event(ring.pop(0))
 
 
 def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):

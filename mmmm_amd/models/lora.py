@@ -284,4 +284,6 @@ def enable_fp8(root: nn.Module) -> int:
             m.f8 = Fp8Weights(m.weight)
             m._wt = None
             n += 1
+    if n and torch.cuda.is_available():
+        torch.cuda.empty_cache()        # the bf16 transposes the quantiser went through were temporaries: hand their blocks back
     return n

