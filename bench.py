@@ -492,10 +492,10 @@ def main():
             alg_bytes = K.prof_last_bytes() / max(n, 1)
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
-            tf = Path(__file__).resolve().parent / 'profiles' / 'r1_gemm_traffic.json'
+            tf = Path(__file__).resolve().parent / 'profiles' / 'r2_gemm_traffic.json'
             if tf.exists():          # PMC passes cannot run inside this process: the committed rocprofv3 measurement
                 tj = json.loads(tf.read_text())
-                traffic, traffic_src = tj['bytes_per_launch'], 'profiles/r1_gemm_traffic.json: ' + tj['source']
+                traffic, traffic_src = tj['bytes_per_launch'], 'profiles/r2_gemm_traffic.json: ' + tj['source']
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
