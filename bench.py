@@ -382,12 +382,19 @@ def main():
     # workload draws new text lengths per batch, so sequence-length tables change from step to step as they do in training)
     batches = [make_batch(w, tok, args.batch, device, seed=1000 * rank + i) for i in range(max(1, args.batches))]
     it = [0]
+    fwd_pool = torch.cuda.MemPool() if os.environ.get('VM_FWD_POOL', '0') == '1' else None
 
     def step():
         batch = batches[it[0] % len(batches)]
         it[0] += 1
         ddp.zero_grad()
-        loss = model.training_step(batch)
+        if fwd_pool is not None:
+            # forward allocations (mostly the activations kept for backward: long-lived) come from their own pool, the backward
+            # pass's temporaries (autograd thread) from the default one: the two lifetimes no longer fragment each other's blocks
+            with torch.cuda.use_mem_pool(fwd_pool):
+                loss = model.training_step(batch)
+        else:
+            loss = model.training_step(batch)
         loss.backward()
         ddp.finish()
         if args.optimizer != 'flat':
@@ -397,6 +404,7 @@ def main():
 
     from mmmm_amd.models.lora import ActivationBudget
     plan = 'every layer recomputed'
+    side_stream_note = ['on']
     if args.checkpointing == 'hbm':
         # planning step (untimed, not a warmup step): peak HBM with every layer checkpointed -> what is left over
         # becomes the activation budget of the following steps
@@ -419,12 +427,23 @@ def main():
         # every step (3D workloads: 850 -> 1570 ms/step, thousands of hipMalloc / hipFree per step), so the budget is cut by
         # the overshoot and the step repeated.
         target = int(args.hbm_fraction * total_hbm)
-        for _ in range(3):
+        for _ in range(5):
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
+            try:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+            except torch.OutOfMemoryError:        # the plan did not even fit: shrink hard and try again
+                if use_dist:
+                    raise                          # (ranks must take the same number of collectives: no local retries)
+                ddp.zero_grad()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                ActivationBudget.limit = int(ActivationBudget.limit * 0.6)
+                if rank == 0:
+                    print(f'[calibrate] out of memory -> budget {ActivationBudget.limit / 2**30:.1f} GB', file=sys.stderr)
+                continue
             r1 = torch.cuda.max_memory_reserved()
             if use_dist:
                 t = torch.tensor([r1], device=device, dtype=torch.int64)
@@ -432,8 +451,22 @@ def main():
                 r1 = int(t.item())
             if rank == 0:
                 print(f'[calibrate] budget {ActivationBudget.limit / 2**30:.1f} GB kept {ActivationBudget.last_plan}: reserved {r1 / 2**30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB (target {target / 2**30:.0f} GB)', file=sys.stderr)
+            if rank == 0 and os.environ.get('VM_MEM_SUMMARY') == '1':
+                print(torch.cuda.memory_summary(abbreviated=True), file=sys.stderr)
             if r1 <= target + (4 << 30) or ActivationBudget.limit == 0:
                 break
+            import mmmm_amd.functional as Fh
+            if Fh.WGRAD_SIDE_STREAM and os.environ.get('VM_WGRAD_STREAM') is None:
+                # First resort: give up the weight-gradient side stream instead of kept layers. Every tensor its kernels read is
+                # withheld from the allocator until that stream has passed it, and the stream owns a block pool of its own: on the
+                # large workloads the pool then holds 50-90 GB more than is ever allocated (phase-grg-3d: reserved 244 GB for an
+                # allocated peak of 188 GB with the side stream, 199 GB for 196 GB without). The stream is worth ~4 % of a step,
+                # a recomputed third of the ViT ~15 %.
+                Fh.WGRAD_SIDE_STREAM = False
+                side_stream_note[0] = 'off (memory: reserved %.0f GB > target %.0f GB with it)' % (r1 / 2**30, target / 2**30)
+                if rank == 0:
+                    print('[calibrate] weight-gradient side stream off', file=sys.stderr)
+                continue
             # reserved memory is ~linear in the kept bytes: interpolate between "nothing kept" (r0) and this plan (r1)
             scale = max(0.0, (target - r0) / max(r1 - r0, 1))
             ActivationBudget.limit = int(ActivationBudget.limit * min(scale, 0.95))
@@ -477,7 +510,7 @@ def main():
             'vs_baseline': None, 'dtype': 'fp8-e4m3 frozen-weight GEMMs (fwd + dgrad), bf16 elsewhere' if args.fp8 else 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
             # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
