@@ -264,6 +264,11 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 
+/* vm_transpose that also accumulates the column sums of `in` atomically into colsum_accum[cols] (fp32): the bias gradient of a trainable
+ * linear is the column sum of dy, which its weight gradient transposes anyway (every nn.Linear of the unfrozen heads under segvol/modeling). */
+int vm_transpose_colsum(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype, float* colsum_accum,
+                        void* stream);
+
 /* LoRA factor gradients: row contraction of a wide streamed operand W [M, C] with a rank-64 operand S [M, 64]
  * (peft lora.Linear backward: dB = s * dy^T t, dA = s * u^T drop(x); functional._Linear.backward).
  *   transpose_out == 0: out[c][n] (C rows, 64 columns, ldo)   = [accumulate ? out : 0] + alpha * sum_m W[m][c] S[m][n]

@@ -394,8 +394,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int64_t ld_in,
                                                    T* __restrict__ out, int64_t ld_out,
                                                    int rows, int cols, const int32_t* nrows_dev,
-                                                   const int32_t* range_dev, int segment) {
+                                                   const int32_t* range_dev, int segment, float* __restrict__ colsum = nullptr) {
   __shared__ T tile[64][64 + 2];
+  __shared__ float csum[4][64];
   int rows_true = rows;
   if (nrows_dev) rows_true = min(rows, *nrows_dev);
   if (range_dev) {
@@ -414,9 +415,18 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
     tile[i][tx] = v;
   }
   __syncthreads();
+  if (colsum) {       // column sums of the input ride along (bias gradient = column sum of dy, which the weight gradient transposes anyway)
+    float a = 0.f;
+    for (int i = ty; i < 64; i += 4) a += Elem<T>::ld(tile[i][tx]);
+    csum[ty][tx] = a;
+  }
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
     if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
+  }
+  if (colsum) {
+    __syncthreads();
+    if (ty == 0 && c0 + tx < cols) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
   }
 }
 
@@ -846,6 +856,17 @@ int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int r
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                            ld_in, (T*)out, ld_out, rows, cols, nrows_dev, (const int32_t*)nullptr, 0));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_transpose_colsum(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype, float* colsum_accum,
+                        void* stream) {
+  if (rows <= 0 || cols <= 0) return VM_OK;
+  if (!colsum_accum) return VM_ERR_BAD_ARG;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
+                                           ld_in, (T*)out, ld_out, rows, cols, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, colsum_accum));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -306,13 +306,22 @@ class _Linear(Function):
                 # unfrozen SAM / iSAM / vg_proj linears): W.grad += dy^T x through the GEMM's residual path, transposes
                 # included, on the side stream — off the critical path, no temporary, no AccumulateGrad add
                 wready = getattr(W, '_vm_grad_ready', None)
+                bias_done = False
                 if (need[base] and not gated and not lora and wready is not None and W.grad is not None and W.grad.dtype == torch.float32
                         and dy.dtype == torch.float32 and W.grad.is_contiguous() and W.grad.shape[1] % 4 == 0):
-                    def run(W=W, wready=wready):
-                        K.gemm(tr(dy), tr(x), residual=W.grad, out=W.grad)
+                    # the bias gradient (column sums of dy) rides along with the transpose of dy when its slot is an fp32 bucket view too
+                    bready = getattr(b, '_vm_grad_ready', None) if (b is not None and need[base + 2]) else None
+                    fuse_b = bready is not None and b.grad is not None and b.grad.dtype == torch.float32 and b.grad.is_contiguous()
+
+                    def run(W=W, wready=wready, b=b, bready=bready, fuse_b=fuse_b):
+                        dyT = K.transpose(dy, pad_to=64, colsum_out=b.grad if fuse_b else None)
+                        K.gemm(dyT, tr(x), residual=W.grad, out=W.grad)
                         wready(W)
+                        if fuse_b:
+                            bready(b)
                     _off_critical_path(run, dy.device, (dy, x))
                     need_w = False
+                    bias_done = fuse_b
                 else:
                     need_w = need[base]
                 dyT = tr(dy) if (need_w or (lora and need[base + 4])) else None
@@ -325,7 +334,7 @@ class _Linear(Function):
                     xd = K.dropout(x, meta.drop_p, meta.drop_seed) if meta.drop_p > 0 else x
                     dA = K.gemm(tr(u), tr(xd))
                     g[base + 3] = dA if s == 1.0 else dA * s
-            if b is not None and need[base + 2]:
+            if b is not None and need[base + 2] and not (not tn_ok and bias_done):
                 if gated:
                     dyT = K.transpose_segment(dy, counts, e)
                     ones = torch.ones(8, dyT.shape[1], dtype=dyT.dtype, device=dyT.device)

@@ -165,15 +165,20 @@ def gemm_f32_mode(mode: int):
 
 
 
-def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = None) -> torch.Tensor:
-    """out[cols, rows_padded] = x^T, zero beyond the true row count (K-contiguous operand of a wgrad GEMM)"""
+def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = None, colsum_out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[cols, rows_padded] = x^T, zero beyond the true row count (K-contiguous operand of a wgrad GEMM). `colsum_out`: fp32 [cols]
+    accumulator that additionally receives the column sums of x (atomically added)"""
     assert x.dim() == 2 and x.stride(1) == 1
     rows, cols = x.shape
     rp = (rows + pad_to - 1) // pad_to * pad_to
     out = torch.empty(cols, rp, dtype=x.dtype, device=x.device)
     if rp > rows:
         out[:, rows:].zero_()
-    hip.call('vm_transpose', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(nrows), stream())
+    if colsum_out is not None:
+        assert nrows is None and colsum_out.dtype == torch.float32 and colsum_out.is_contiguous() and colsum_out.numel() == cols
+        hip.call('vm_transpose_colsum', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(colsum_out), stream())
+    else:
+        hip.call('vm_transpose', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(nrows), stream())
     return out
 
 
