@@ -423,7 +423,16 @@ __global__ __launch_bounds__(256) void tn_reduce_k(const float* __restrict__ ws,
   const int64_t sstride = (int64_t)c_pad * 64;
   f32x4_t a = {0.f, 0.f, 0.f, 0.f};
   int s = 0;
-  for (; s + 4 <= splits; s += 4) {          // four loads in flight; the summation order stays s = 0, 1, 2, ...
+  // the kernel is pure load latency (a few MB through 112-960 workgroups): keep eight loads in flight per thread; the summation
+  // order stays s = 0, 1, 2, ... (deterministic)
+  for (; s + 8 <= splits; s += 8) {
+    f32x4_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4_t*>(src + (s + j) * sstride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j];
+  }
+  for (; s + 4 <= splits; s += 4) {
     const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (s + 0) * sstride);
     const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (s + 1) * sstride);
     const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (s + 2) * sstride);
