@@ -127,6 +127,10 @@ typedef struct vm_gemm_args {
                                                 pre-zeroed fp32 C with atomics (tiny M x N, long K: the weight gradients of
                                                 the mask-decoder hyper-network products). Needs out_dtype VM_F32, no
                                                 activation, K2 == 0. 0 / 1 = off. */
+  int32_t b_nn;                              /* vm_gemm_bf16 only. != 0: B (and B_1) are given as [K, N] — the contraction index is the ROW,
+                                                ldb the row pitch — i.e. a weight W [N_w, K_w] as it sits in HBM is the operand of the input
+                                                gradient dx [M, K_w] = dy [M, N_w] . W with K = N_w, N = K_w: no transposed copy of the frozen
+                                                weights (35 GB for the 7B decoder + ViT-E) is kept. bf16 output, N % 8 == 0, no split-K. */
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);

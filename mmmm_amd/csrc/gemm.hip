@@ -446,7 +446,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (segmented && !a->B_1) return VM_ERR_BAD_ARG;
   // 32-bit buffer offsets inside one tile: 128 rows * pitch must fit
   if ((int64_t)BM * a->lda * esz + (int64_t)a->K * esz >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
-  if ((int64_t)BN * a->ldb * esz + (int64_t)a->K * esz >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
+  if (!a->b_nn && (int64_t)BN * a->ldb * esz + (int64_t)a->K * esz >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
 
   GemmParams p;
   p.A = (const char*)a->A; p.lda = a->lda;
@@ -464,6 +464,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
   p.ksplit = 1; p.kchunk = a->K;
   p.row_scale = nullptr; p.col_scale0 = p.col_scale1 = nullptr;
+  p.b_nn = 0;
   if (a->ksplit > 1) {
     if (a->out_dtype != VM_F32 || a->act != VM_ACT_NONE || a->K2 != 0) return VM_ERR_BAD_ARG;
     const int kt = a->K / bke;
@@ -491,9 +492,15 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
-  const int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
+  int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
+  if (a->b_nn) {
+    // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
+    if (esz != 2 || a->out_dtype != VM_BF16 || p.ksplit > 1 || a->N % 8 || (int64_t)a->K * a->ldb * 2 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
+    if (!big) big = 256;
+    p.b_nn = 1;
+  }
   if (big) {
-    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 0, stream);
+    const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
     if (rc != VM_OK) return rc;
   } else if (esz == 4 && bm64) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
@@ -558,6 +565,7 @@ int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_
   p.act = a->act;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
   p.ksplit = 1; p.kchunk = a->K;
+  p.b_nn = 0;
   p.row_scale = row_scale; p.col_scale0 = col_scale; p.col_scale1 = col_scale_1 ? col_scale_1 : col_scale;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   int big = big_tile_rows(a->M, a->N, a->K / 2 + a->K2, segmented);          /* rounds x cost in bf16-equivalent K-tiles */

@@ -15,6 +15,7 @@
 //     MFMA segment while the other is in its LDS-read / DMA-issue segment.
 #include "vm_common.hpp"
 #include "gemm_common.hpp"
+#include "vm_tile.hpp"
 #include <type_traits>
 
 namespace {
@@ -47,6 +48,38 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, int ld_b
     }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_half + inst * 1024), 16, voff, koff, 0, 0);
   }
+}
+
+// NN form of the weight operand (dgrad dx = dy W with W [N, K] as stored: the contraction index is the ROW of the stored matrix).
+// LDS-DMA of one half-tile = 64 contraction rows x (4 wave columns x 32 output columns) bf16 = [64][256 B], image (b) of the guide's
+// transposed-read recipe (vm_tile.hpp: tile_off / swz), 16 wave-instructions of 1 KiB = 4 rows each, 2 per wave. `row0` = first
+// contraction row of the K-tile, `cols_valid` = output columns of this tile that exist (chunks past them read zero).
+__device__ __forceinline__ void stage_half_nn(__amdgpu_buffer_rsrc_t rsrc, int ld_bytes, int row0, int half, int cols_valid, char* lds_half,
+                                              int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = wave * 2 + i;
+    const int row = inst * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ swz(row);
+    const int col = (chunk >> 2) * 64 + half * 32 + (chunk & 3) * 8;           // output column inside the 256-column tile
+    const int voff = (col + 8 <= cols_valid) ? (row0 + row) * ld_bytes + col * 2 : 0x7FFFFFF0;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_half + inst * 1024), 16, voff, 0, 0, 0);
+  }
+}
+
+// weight fragment of the 16x16x32 MFMA out of the NN image: lane (frow = column, fq) gets rows kbase + 8 fq + 0..7 of column
+// 16-block `c0` (in 16-byte chunks: c0, c0 + 1) through two ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group each)
+__device__ __forceinline__ bf16x8_t frag_tr16(const char* tile, int kbase, int c0, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int q = i >> 2, pp = i & 3;
+  const int chunk = c0 + (pp >> 1);
+  const int rowA = kbase + 8 * g + q, rowB = rowA + 4;
+  const char* a = tile + tile_off(rowA, chunk) + ((pp & 1) << 3);
+  const char* c = tile + tile_off(rowB, chunk) + ((pp & 1) << 3);
+  u16x4_t lo = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a)));
+  u16x4_t hi = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(c)));
+  u16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, r);
 }
 
 #define VM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -123,8 +156,9 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
 // structure, 12 instead of 16 MFMAs per phase). The 192-row tile exists for tile-count quantisation: [6280 x 1792] is 175
 // tiles of 256 rows (68 % of one round over 256 CUs) but 231 tiles of 192 rows, [6280 x 5376] is 525 (3 rounds) vs 693
 // (3 rounds of 0.75 the work).
-template <bool OUT_F32, int MI, bool F8 = false>
+template <bool OUT_F32, int MI, bool F8 = false, bool BNN = false>
 __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
+  static_assert(!(F8 && BNN), "the NN weight form exists for bf16 only");
   constexpr int BMT = 64 * MI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -144,7 +178,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
 
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
   const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
-  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
+  // NT: rows n0 .. n0 + ncols of B [N, K]; NN: all K contraction rows of B [K, N], shifted to output column n0
+  const __amdgpu_buffer_rsrc_t rB = BNN ? make_rsrc(Bw, (int64_t)n0 * 2, (p.dbg & 1) ? 0 : (int)(((int64_t)p.K * ldb_b - (int64_t)n0 * 2)))
+                                        : make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
   // F8: the main operands are e4m3 bytes — a 128-byte LDS row holds 128 k instead of 64, everything else (DMA, swizzle, phases) is
   // unchanged; the LoRA extension tiles stay bf16
   const int kt_ext = p.K2 / 64, kt_main = F8 ? p.K / 128 : p.K / 64, kt_total = kt_ext + kt_main;
@@ -162,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     const bool ext = t < kt_ext;
     const int koff = (ext ? t : t - kt_ext) * 128;
     if (h < 2) stage_half<0, MI>(ext ? rA2 : rA, ext ? lda2_b : lda_b, koff, h, dst, wave, lane);
+    else if (BNN && !ext) stage_half_nn(rB, ldb_b, (t - kt_ext) * 64, h - 2, ncols, dst, wave, lane);
     else stage_half<1>(ext ? rB2 : rB, ext ? ldb2_b : ldb_b, koff, h - 2, dst, wave, lane);
   };
 
@@ -192,6 +229,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     for (int j = 0; j < 2; ++j) {
       bF[nh][j][0] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k0);
       bF[nh][j][1] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k1);
+    }
+  };
+  auto read_b_nn = [&](const char* st, int nh) {   // NN image of B-h{nh}: column 16-blocks wn * 4 + 2 j (in chunks), rows 32 ks + 8 fq ..
+    const char* base = st + (2 + nh) * HALF_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bF[nh][j][0] = frag_tr16(base, 0, wn * 4 + 2 * j, lane);
+      bF[nh][j][1] = frag_tr16(base, 32, wn * 4 + 2 * j, lane);
     }
   };
   auto mma = [&](int mh, int nh, auto f8_tag) {
@@ -231,11 +276,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   // EVERY wave's R segment is sufficient for both rows (row 0 merely retires one interval early) and keeps the steady
   // state free of wave-dependent branches. The loop is peeled (HN = "a next K-tile exists") so it has no data-dependent
   // branches between MFMA clusters either.
-  auto ktile = [&](int t, auto hn_tag, auto f8_tag) {
+  auto ktile = [&](int t, auto hn_tag, auto f8_tag, auto nn_tag) {
     constexpr bool HN = decltype(hn_tag)::value;
+    constexpr bool NNB = decltype(nn_tag)::value;      // this K-tile's weight image is the NN one (main tiles of a BNN launch)
     const char* st = smem + (t & 1) * STAGE_BYTES2;
     // ---- phase 1: quadrant (0,0); needs A-h0, B-h0; issues A-h0'; retires B-h1 of this tile
-    read_a(st, 0); read_b(st, 0);
+    read_a(st, 0);
+    if constexpr (NNB) read_b_nn(st, 0); else read_b(st, 0);
     if (HN) stage(t + 1, 0);
     if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(2);
     __builtin_amdgcn_sched_barrier(0);
@@ -244,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     POST_MMA_BARRIER();
     // ---- phase 2: quadrant (0,1); needs B-h1; issues B-h0'; retires A-h1 of this tile
-    read_b(st, 1);
+    if constexpr (NNB) read_b_nn(st, 1); else read_b(st, 1);
     if (HN) stage(t + 1, 2);
     if (HN) VM_WAIT_VMCNT(4); else VM_WAIT_VMCNT(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -295,12 +342,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   // with the scale in the loop body the compiler hoists the 128 loop-invariant mask hashes and spills them
   int t = 0;
   const std::integral_constant<bool, F8> main_kind{};
+  const std::integral_constant<bool, BNN> main_nn{};
   if (kt_ext > 0) {
-    for (; t < kt_ext; ++t) ktile(t, std::true_type{}, std::false_type{});
+    for (; t < kt_ext; ++t) ktile(t, std::true_type{}, std::false_type{}, std::false_type{});
     ext_scale();
   }
-  for (; t + 1 < kt_total; ++t) ktile(t, std::true_type{}, main_kind);
-  ktile(kt_total - 1, std::false_type{}, main_kind);
+  for (; t + 1 < kt_total; ++t) ktile(t, std::true_type{}, main_kind, main_nn);
+  ktile(kt_total - 1, std::false_type{}, main_kind, main_nn);
 #ifndef VM_G256_NO_STAGGER
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #endif
@@ -330,15 +378,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
 
 // called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles; f8 != 0: e4m3 main operands (vm_gemm_fp8)
 extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, void* stream) {
+  // f8: 0 bf16 NT, 1 e4m3 NT, 2 bf16 with the weight in NN form (p.b_nn)
   GemmParams p = *(const GemmParams*)params;
   if (tile_rows != 256 && tile_rows != 192) return VM_ERR_BAD_ARG;
   p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
   p.tiles_n = (p.N + 255) / 256;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* fns[8] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+    const void* fns[10] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
                           (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
-                          (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>};
+                          (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>,
+                          (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>};
     for (const void* f : fns)
       if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
     attr_set = true;
@@ -346,7 +396,11 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   hipStream_t st = (hipStream_t)stream;
 #define VM_G256_LAUNCH(O, M_, F_) hipLaunchKernelGGL((gemm256_k<O, M_, F_>), grid, block, LDS_BYTES2, st, p)
-  if (f8) {
+  if (f8 == 2) {
+    if (out_f32) return VM_ERR_UNSUPPORTED;
+    if (tile_rows == 256) hipLaunchKernelGGL((gemm256_k<false, 4, false, true>), grid, block, LDS_BYTES2, st, p);
+    else hipLaunchKernelGGL((gemm256_k<false, 3, false, true>), grid, block, LDS_BYTES2, st, p);
+  } else if (f8) {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
   } else {

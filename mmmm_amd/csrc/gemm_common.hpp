@@ -26,6 +26,7 @@ struct GemmParams {
   // fp8 main product (gemm256_k<.., F8 = true>): A / B hold e4m3 bytes, K counts fp8 elements; the epilogue multiplies the
   // accumulators by row_scale[m] * col_scale[n] (per-row activation scales, per-output-channel weight scales of each segment)
   const float* row_scale; const float* col_scale0; const float* col_scale1;
+  int b_nn;             // gemm256_k<.., BNN>: the main B operand is stored [contraction][output column] (a weight as it sits in HBM, for dx = dy W)
   int ksplit, kchunk;   // split-K (fp32 atomics into a zeroed C): blockIdx.y owns K range [y*kchunk, (y+1)*kchunk)
   int dbg;   // timing experiments only: bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
 };

@@ -123,6 +123,7 @@ def _hold_until_backward_ends(t: torch.Tensor):
         torch.autograd.Variable._execution_engine.queue_callback(_HELD.clear)
     _HELD.append(t)
 WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
+NN_DGRAD = os.environ.get('VM_NN_DGRAD', '1') == '1'       # 0: resident transposed copies of the frozen weights + NT dgrad (round 1)
 
 
 def _off_critical_path(fn, device, keep_alive):
@@ -267,6 +268,13 @@ class _Linear(Function):
                               a2=K.scale_rows(u, inv_dy) if lora else None, b2=K.scale_rows(At0, f0.inv_swt) if lora else None,
                               b2_1=K.scale_rows(At1, f1.inv_swt) if (lora and gated) else None, alpha2=s if lora else 1.0, counts=cnt,
                               drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed, out_dtype=x.dtype)
+        elif need[1] and Wt0 is None and NN_DGRAD and x.dtype == torch.bfloat16 and dy.shape[1] % 64 == 0 and x.shape[1] % 8 == 0:
+            # dx = dy W with W as it sits in HBM (the 256-column kernel reads the weight through transposed LDS reads): no transposed
+            # copy of the weight, resident or per use
+            At0 = (meta.At0 if meta.At0 is not None else _t(A0)) if lora else None
+            At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
+            g[1] = K.gemm(dy, W0.detach(), w1=W1.detach() if gated else None, b_nn=True, a2=u, b2=At0, b2_1=At1,
+                          alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
         elif need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None

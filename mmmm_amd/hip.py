@@ -43,6 +43,7 @@ class GemmArgs(C.Structure):
         ('drop_p', C.c_float), ('drop_seed', C.c_uint64),
         ('alpha', C.c_float),
         ('ksplit', C.c_int32),
+        ('b_nn', C.c_int32),
     ]
 
 

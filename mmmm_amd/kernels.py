@@ -35,16 +35,21 @@ def gemm(
     out: torch.Tensor | None = None, out_dtype: torch.dtype | None = None,
     act: int = hip.ACT_NONE,
     counts: torch.Tensor | None = None, split: int = -1,
-    drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False,
+    drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False, b_nn: bool = False,
 ) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
 
     `w1`/`b2_1`/`bias1`: weights of the second row segment (token-type gated experts); the segment
     boundary is `split` (host) or `counts[0]` with `counts[1]` valid rows (device int32 tensor).
     """
-    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
-    M, K = a.shape
-    N = w.shape[0]
+    if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
+        assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.dtype == torch.bfloat16 and out is None, (a.shape, w.shape)
+        M, K = a.shape
+        N = w.shape[1]
+    else:
+        assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1], (a.shape, w.shape)
+        M, K = a.shape
+        N = w.shape[0]
     f32 = a.dtype == torch.float32
     assert w.dtype == a.dtype
     if out_dtype is None:
@@ -95,6 +100,7 @@ def gemm(
     g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF
     g.alpha = 1.0
     g.ksplit = ksplit
+    g.b_nn = 1 if b_nn else 0
     hip.call('vm_gemm_f32' if f32 else 'vm_gemm_bf16', C.addressof(g), stream())
     return out
 

@@ -152,6 +152,8 @@ class Linear(nn.Module):
         """transposed copy [in, out] of a FROZEN weight (kept resident: 288 GB HBM buys a plain NT dgrad)"""
         if self.weight.requires_grad or self.f8 is not None:
             return None
+        if Fh.NN_DGRAD and self.weight.dtype == torch.bfloat16 and self.out_features % 64 == 0 and self.in_features % 8 == 0:
+            return None          # the dgrad GEMM reads W itself (functional._Linear.backward, `b_nn`): no resident transpose
         if self._wt is None or self._wt.device != self.weight.device or self._wt.dtype != self.weight.dtype:
             self._wt = K.transpose(self.weight.detach())
         return self._wt

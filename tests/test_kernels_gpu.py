@@ -813,3 +813,23 @@ def test_upsample_trilinear_matches_aten(dev, K, inp, out):
     # 5-D form [P, M, d, h, w] as the instance head uses it
     x5 = torch.randn(2, 3, *inp, generator=g).to(dev)
     assert rel_err(Fh.upsample_trilinear(x5, out), F.interpolate(x5, out, mode='trilinear')) < 1e-6
+
+
+@pytest.mark.parametrize('M,N,Kc', [(300, 520, 256), (6280, 1792, 15360), (3648, 4096, 11008), (1000, 15360, 1792)])
+def test_gemm_nn_weight_form_equals_nt(dev, K, M, N, Kc):
+    """dx = dy W with the weight read as stored (`b_nn`: [contraction, output] rows through transposed LDS reads) against the NT kernel on the
+    transposed copy: same operand values in the same k order -> bit-identical, with two row segments, K-extension, dropout mask"""
+    torch.manual_seed(4)
+    dy = torch.randn(M, Kc, device=dev).bfloat16()
+    W = (torch.randn(Kc, N, device=dev) / Kc ** 0.5).bfloat16()            # [contraction, output]
+    W1 = (torch.randn(Kc, N, device=dev) / Kc ** 0.5).bfloat16()
+    want = K.gemm(dy, K.transpose(W))
+    got = K.gemm(dy, W, b_nn=True)
+    assert torch.equal(got, want)
+    u = (torch.randn(M, 64, device=dev) * 0.3).bfloat16()
+    At, At1 = (torch.randn(N, 64, device=dev) * 0.1).bfloat16(), (torch.randn(N, 64, device=dev) * 0.1).bfloat16()
+    counts = torch.tensor([M // 3, M - 5, 0, 0], dtype=torch.int32, device=dev)
+    kw = dict(a2=u, b2=At, b2_1=At1, alpha2=0.7, counts=counts, drop_p=0.1, drop_seed=77)
+    want = K.gemm(dy, K.transpose(W), w1=K.transpose(W1), **kw)
+    got = K.gemm(dy, W, w1=W1, b_nn=True, **kw)
+    assert torch.equal(got[:M - 5], want[:M - 5])
