@@ -231,13 +231,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
       bF[nh][j][1] = *reinterpret_cast<const bf16x8_t*>(base + j * 2048 + off_k1);
     }
   };
-  auto read_b_nn = [&](const char* st, int nh) {   // NN image of B-h{nh}: column 16-blocks wn * 4 + 2 j (in chunks), rows 32 ks + 8 fq ..
+  // NN image of B-h{nh}: column 16-blocks wn * 4 + 2 j (in chunks), rows 32 ks + 8 fq + 0..7 as two 4-row transposed reads. The eight
+  // per-lane byte offsets (j, ks, upper / lower 4 rows) are loop invariants: computed once here, the halves and stages differ by constants.
+  int nn_off[2][2][2];
+  if constexpr (BNN) {
+    const int gi = lane & 15, gg = lane >> 4, gq = gi >> 2, gp = gi & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+          nn_off[j][ks][hl] = tile_off(32 * ks + 8 * gg + gq + 4 * hl, wn * 4 + 2 * j + (gp >> 1)) + ((gp & 1) << 3);
+  }
+  auto read_b_nn = [&](const char* st, int nh) {
     const char* base = st + (2 + nh) * HALF_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bF[nh][j][0] = frag_tr16(base, 0, wn * 4 + 2 * j, lane);
-      bF[nh][j][1] = frag_tr16(base, 32, wn * 4 + 2 * j, lane);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u16x4_t lo = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + nn_off[j][ks][0])));
+        const u16x4_t hi = __builtin_bit_cast(u16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + nn_off[j][ks][1])));
+        const u16x8_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bF[nh][j][ks] = __builtin_bit_cast(bf16x8_t, r);
+      }
   };
   auto mma = [&](int mh, int nh, auto f8_tag) {
     if constexpr (decltype(f8_tag)::value) {

@@ -123,7 +123,11 @@ def _hold_until_backward_ends(t: torch.Tensor):
         torch.autograd.Variable._execution_engine.queue_callback(_HELD.clear)
     _HELD.append(t)
 WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
-NN_DGRAD = os.environ.get('VM_NN_DGRAD', '1') == '1'       # 0: resident transposed copies of the frozen weights + NT dgrad (round 1)
+# 1: dgrad reads the weight as stored (`b_nn` form of the 256-column GEMM) and no transposed copies of the frozen weights are kept
+# (-35 GB). Bit-identical to the NT form but currently 0.6-0.85x its rate (192-row tiles only, 64-byte DMA segments, twice the LDS
+# read instructions): the step loses more than the freed memory buys (model-hr-3d: every layer kept, yet 3.47 vs 3.59 images/s;
+# phase-vg-448 445 vs 359 ms), so the default stays the NT dgrad on resident transposes.
+NN_DGRAD = os.environ.get('VM_NN_DGRAD', '0') == '1'
 
 
 def _off_critical_path(fn, device, keep_alive):
