@@ -496,7 +496,8 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
     if (esz != 2 || a->out_dtype != VM_BF16 || p.ksplit > 1 || a->N % 8 || (int64_t)a->K * a->ldb * 2 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
-    big = 192;            // the 256-row form of the NN kernel spills (24 VGPRs, in the loop); the 192-row form has room
+    { static int nt = -1; if (nt < 0) { const char* e = getenv("VM_NN_TILE"); nt = e ? atoi(e) : 192; }
+      if (nt == 192 || nt == 256) big = nt; else if (!big) big = 256; }   // default 192: the 256-row NN form spills 15 VGPRs
     p.b_nn = 1;
   }
   if (big) {
