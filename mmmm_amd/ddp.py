@@ -194,6 +194,16 @@ class BucketedGradAllReduce:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
+        if not self.collectives:
+            # several backward passes before one finish() (local gradient accumulation): side accumulators filled after their bucket
+            # was launched are folded now (a fold of zeroed accumulators is a no-op). With collectives ONE backward pass per finish()
+            # is assumed, as for torch's DDP without no_sync(): a bucket is reduced the first time it completes.
+            for st in self._step_streams:
+                cur = torch.cuda.current_stream(st.device)
+                if st != cur:
+                    cur.wait_stream(st)
+            for bi in self._f32_entries:
+                self._fold_f32(bi)
         consumer = None
         for st in self._step_streams:
             if consumer is None:
