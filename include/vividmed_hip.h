@@ -131,6 +131,8 @@ typedef struct vm_gemm_args {
                                                 ldb the row pitch — i.e. a weight W [N_w, K_w] as it sits in HBM is the operand of the input
                                                 gradient dx [M, K_w] = dy [M, N_w] . W with K = N_w, N = K_w: no transposed copy of the frozen
                                                 weights (35 GB for the 7B decoder + ViT-E) is kept. bf16 output, N % 8 == 0, no split-K. */
+  int32_t f32_split;                         /* vm_gemm_f32 only: arithmetic of THIS call. 0 = the process default (vm_gemm_f32_mode),
+                                                1 = exact f32 MFMA, 2 = split-bf16 with 3 products, 3 = split-bf16 with 6 products. */
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);

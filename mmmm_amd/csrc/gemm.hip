@@ -489,6 +489,8 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   const int grid = p.tiles_m * p.tiles_n;
   const int kind = esz == 2 ? VM_PROF_GEMM_BF16 : VM_PROF_GEMM_F32;
+  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
+  const int fmode = a->f32_split == 0 ? f32_mode() : (a->f32_split == 1 ? 0 : a->f32_split);
 
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
@@ -505,13 +507,13 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
     if (rc != VM_OK) return rc;
   } else if (esz == 4 && bm64) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
-    switch (f32_mode()) {
+    switch (fmode) {
       case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 0>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
       case 2: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 2>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
       default: hipLaunchKernelGGL((gemm_nt_k<4, true, 64, 3>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, p); break;
     }
   } else if (esz == 4) {
-    switch (f32_mode()) {
+    switch (fmode) {
       case 0: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 0>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
       case 2: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 2>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;
       default: hipLaunchKernelGGL((gemm_nt_k<4, true, 128, 3>), dim3(grid, p.ksplit), dim3(256), LDS_BYTES, (hipStream_t)stream, p); break;

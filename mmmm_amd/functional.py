@@ -72,6 +72,8 @@ class LinearMeta:
     # fp8 mode of the frozen base weight (models/lora.py Fp8Weights per expert): e4m3 copies of W and W^T with their scales
     f8_0: object = None
     f8_1: object = None
+    # fp32 operands: arithmetic of this layer's three GEMMs (kernels.gemm `f32_split`; 0 = the process default)
+    f32_split: int = 0
 
 
 def _t(w: torch.Tensor) -> torch.Tensor:
@@ -237,7 +239,7 @@ class _Linear(Function):
                 xp, W0p, w1=W1p if meta.gated else None,
                 a2=t, b2=B0 if lora else None, b2_1=B1 if (lora and meta.gated) else None, alpha2=meta.lora_scale if lora else 1.0,
                 bias=b0, bias1=b1 if meta.gated else None, residual=residual,
-                counts=counts if meta.gated else None, act=meta.act, out_dtype=meta.out_dtype,
+                counts=counts if meta.gated else None, act=meta.act, out_dtype=meta.out_dtype, f32_split=meta.f32_split,
             )
         ctx.meta, ctx.lora = meta, lora
         ctx.save_for_backward(x, t, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
@@ -286,7 +288,8 @@ class _Linear(Function):
             At0 = (meta.At0 if meta.At0 is not None else _t(A0)) if lora else None
             At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
             g[1] = K.gemm(dyp, wt0, w1=wt1, a2=u, b2=At0, b2_1=At1,
-                          alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
+                          alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed,
+                          f32_split=meta.f32_split)
         if ctx.has_residual and need[2]:
             g[2] = dy
             if WGRAD_SIDE_STREAM and dy.is_cuda:
@@ -327,7 +330,7 @@ class _Linear(Function):
 
                     def run(W=W, wready=wready, b=b, bready=bready, fuse_b=fuse_b):
                         dyT = K.transpose(dy, pad_to=64, colsum_out=b.grad if fuse_b else None)
-                        K.gemm(dyT, tr(x), residual=W.grad, out=W.grad)
+                        K.gemm(dyT, tr(x), residual=W.grad, out=W.grad, f32_split=meta.f32_split)
                         wready(W)
                         if fuse_b:
                             bready(b)
@@ -338,7 +341,7 @@ class _Linear(Function):
                     need_w = need[base]
                 dyT = tr(dy) if (need_w or (lora and need[base + 4])) else None
                 if need_w:
-                    g[base] = K.gemm(dyT, tr(x))
+                    g[base] = K.gemm(dyT, tr(x), f32_split=meta.f32_split)
                 if lora and need[base + 4]:
                     dB = K.gemm(dyT, tr(t))
                     g[base + 4] = dB if s == 1.0 else dB * s

@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ('alpha', C.c_float),
         ('ksplit', C.c_int32),
         ('b_nn', C.c_int32),
+        ('f32_split', C.c_int32),
     ]
 
 

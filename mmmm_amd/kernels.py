@@ -36,11 +36,13 @@ def gemm(
     act: int = hip.ACT_NONE,
     counts: torch.Tensor | None = None, split: int = -1,
     drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False, b_nn: bool = False,
+    f32_split: int = 0,
 ) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
 
     `w1`/`b2_1`/`bias1`: weights of the second row segment (token-type gated experts); the segment
     boundary is `split` (host) or `counts[0]` with `counts[1]` valid rows (device int32 tensor).
+    `f32_split` (fp32 operands): arithmetic of this call — 0 process default, 1 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products.
     """
     if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
         assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.dtype == torch.bfloat16 and out is None, (a.shape, w.shape)
@@ -101,6 +103,7 @@ def gemm(
     g.alpha = 1.0
     g.ksplit = ksplit
     g.b_nn = 1 if b_nn else 0
+    g.f32_split = f32_split if f32 else 0
     hip.call('vm_gemm_f32' if f32 else 'vm_gemm_bf16', C.addressof(g), stream())
     return out
 

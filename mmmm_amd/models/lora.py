@@ -120,6 +120,7 @@ class Linear(nn.Module):
         self._wt: torch.Tensor | None = None
         self._lora_t: tuple | None = None      # (At [in, r], Bt [r, out], version key) — see LoraTransposes
         self.f8: Fp8Weights | None = None      # set by enable_fp8(): e4m3 copies of the frozen weight
+        self.f32_split = 0                     # fp32 layers: arithmetic of this layer's GEMMs (kernels.gemm `f32_split`; 0 = default)
         self._site = StepState.new_site()
         nn.init.normal_(self.weight, std=0.02)
 
@@ -169,6 +170,7 @@ class Linear(nn.Module):
     def meta(self, gated: bool = False) -> Fh.LinearMeta:
         m = Fh.LinearMeta(gated=gated)
         m.f8_0 = self.f8
+        m.f32_split = self.f32_split
         if self.lora_cfg is not None:
             m.lora_scale = self.lora_cfg.scale
             if torch.is_grad_enabled():
