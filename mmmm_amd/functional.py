@@ -330,7 +330,7 @@ class _Linear(Function):
 
                     def run(W=W, wready=wready, b=b, bready=bready, fuse_b=fuse_b):
                         dyT = K.transpose(dy, pad_to=64, colsum_out=b.grad if fuse_b else None)
-                        K.gemm(dyT, tr(x), residual=W.grad, out=W.grad, f32_split=meta.f32_split)
+                        K.gemm(dyT, tr(x), out=W.grad, accumulate=True, f32_split=meta.f32_split)
                         wready(W)
                         if fuse_b:
                             bready(b)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import math
 
 import torch
 
@@ -36,12 +37,14 @@ def gemm(
     act: int = hip.ACT_NONE,
     counts: torch.Tensor | None = None, split: int = -1,
     drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False, b_nn: bool = False,
-    f32_split: int = 0,
+    f32_split: int = 0, accumulate: bool = False, ksplit_override: int | None = None,
 ) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
 
     `w1`/`b2_1`/`bias1`: weights of the second row segment (token-type gated experts); the segment
     boundary is `split` (host) or `counts[0]` with `counts[1]` valid rows (device int32 tensor).
+    `accumulate` (with an fp32 `out`): out += product — through the split-K atomics when the output is a handful of tiles with a
+    long contraction, else through the residual path of the epilogue.
     `f32_split` (fp32 operands): arithmetic of this call — 0 process default, 1 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products.
     """
     if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
@@ -63,11 +66,21 @@ def gemm(
     if out is not None:
         out_dtype = out.dtype
     # (`out_is_zero`: the caller passes a ZEROED fp32 `out`, which the split-K form may accumulate into)
-    if ((out is None or out_is_zero) and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
+    if accumulate:
+        assert out is not None and out.dtype == torch.float32 and residual is None
+    if ((out is None or out_is_zero or accumulate) and out_dtype == torch.float32 and act == hip.ACT_NONE and a2 is None and counts is None and split < 0
             and tiles <= 48 and K >= 1024):
         # a handful of output tiles with a long contraction (weight gradients of the fp32 grounding heads). Only for small
         # outputs: the fp32 atomic epilogue runs at ~60 G atomics/s and already costs more than it saves at 150 tiles.
-        ksplit = max(1, min(64, K // (4 * (32 if f32 else 64)), -(-400 // tiles)))
+        # One workgroup walking all of K alone costs ~38 ns per K element (fp32 operands; ~7 ns bf16); S splits divide that by S but
+        # add M*N*S fp32 atomics at ~60 G/s: the optimum is S = sqrt(t_K / t_atomics) (measured: [384 x 768 x 12544] 457 us
+        # unsplit, 144 us with 23 splits, the model's 10 splits ~95 us; [768 x 768 x 3136] 118 us unsplit = 115 us with 11 splits)
+        best = math.sqrt((2256.0 if f32 else 400.0) * K / (M * N))
+        ksplit = max(1, min(64, K // (4 * (32 if f32 else 64)), -(-512 // tiles), int(best + 0.5)))
+    if ksplit_override is not None:      # tools/bench_gemm_f32.py sweeps the split count
+        ksplit = ksplit_override
+    if accumulate and ksplit <= 1:
+        residual = out
     if out is None:
         al = 8 if out_dtype == torch.bfloat16 else 4
         Np = (N + al - 1) // al * al                 # keep ldc aligned for the vector stores of the epilogue

@@ -163,6 +163,20 @@ def test_gemm_split_k_small_output(dev, K, dt):
     assert rel_err(out, ref) < (2e-6 if dt == torch.float32 else 1e-5)
 
 
+@pytest.mark.parametrize('M,N,Kd', [(384, 768, 12544), (768, 768, 3136), (2304, 768, 3136), (96, 40, 640)])
+@pytest.mark.parametrize('split', [0, 2])
+def test_gemm_f32_accumulate_into_existing_output(dev, K, M, N, Kd, split):
+    """out += a w^T (the fp32 heads' weight gradients accumulate straight into their bucket slots): the few-tiles / long-K shapes go
+    through the split-K atomics ON TOP of the existing content, the others through the epilogue's residual path"""
+    a = torch.randn(M, Kd, device=dev)
+    w = torch.randn(N, Kd, device=dev) / math.sqrt(Kd)
+    out = torch.randn(M, N, device=dev)
+    ref = out.double() + a.double() @ w.double().T
+    got = K.gemm(a, w, out=out, accumulate=True, f32_split=split)
+    assert got.data_ptr() == out.data_ptr()
+    assert rel_err(out, ref) < (2e-6 if split == 0 else 1.5e-5)
+
+
 def test_transpose(dev, K):
     for dt in (torch.bfloat16, torch.float32):
         x = torch.randn(130, 200, device=dev).to(dt)
