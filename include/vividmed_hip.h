@@ -265,8 +265,8 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
                      int n, void* dweight, int64_t ld_w, int cols, int dtype, void* stream);
 
 /* out[c, r] = in[r, c]; columns >= rows_true (device count, optional) are zero-filled
- * up to `rows` so that the result can be the K-contiguous operand of an NT GEMM
- * (weight-gradient GEMMs contract over tokens). */
+ * up to `rows` — and on to min(ld_out, rows rounded up to 64): the pad columns of a K-padded output row need no separate
+ * fill — so that the result can be the K-contiguous operand of an NT GEMM (weight-gradient GEMMs contract over tokens). */
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 
@@ -391,6 +391,29 @@ int vm_dice_focal_bwd(const float* x, const unsigned char* target, int rows, int
  * column of row r. max_cols: host upper bound of the column counts (> 64 -> VM_ERR_UNSUPPORTED, solve on the host). */
 int vm_lsap_f32(const float* cost, int64_t ld_prob, int64_t ld_row, const int32_t* dims_dev, int32_t* col4row,
                 int64_t ld_out, int n_prob, int max_cols, void* stream);
+
+/* Cost matrices of the box-only Hungarian matching of every target of every sample in ONE launch:
+ * InstanceSamLoss._match_instances, segvol/modeling/sam.py:178-250 (per target: box_loss(reduce_batch=False) :148-160 of every
+ * query against every label box + the discriminator cost of a positive; the cost of a negative on the dummy columns that make the
+ * matrix square). desc_dev[p] = {reg, logit, label, n_pos, n_col, nq} (int64; reg -> fp32 [nq, 6] centre-size rows of the
+ * target's instance queries, logit -> fp32 [nq], label -> fp32 [n_pos, 6]); cost[p] is [rows x width] fp32, zero outside
+ * [nq x n_col] — the layout vm_lsap_f32 reads. match_ce != 0: discriminator cost = disc_weight * (1 - p | p); else
+ * disc_weight * focal(logit, 1 | 0) with gamma / alpha (alpha < 0: none). */
+int vm_box_match_cost(const int64_t* desc_dev, int n_problems, float* cost, int rows, int width, float l1_weight, float giou_weight,
+                      float disc_weight, int match_ce, float gamma, float alpha, void* stream);
+
+/* Instance losses of one sample (InstanceSamLoss.compute_loss, sam.py:252-361, branch without instance masks) in one launch
+ * each way. logit fp32 [n_targets, n_queries]; reg fp32 [n_targets, 1 + n_queries, 6] (row 0 of a target = its semantic box:
+ * not part of the loss); label fp32 [n_boxes, 6]; match int64 [n_targets, n_queries] = index of the matched label box or < 0.
+ * out6 = { focal mean over all entries (label = matched; alpha), focal mean of matched entries vs 1 (no alpha; log only),
+ *          focal mean of unmatched entries vs 0 (no alpha; log only), l1 mean over matched pairs (F.l1_loss),
+ *          1 - mean box_pair_giou over matched pairs [monai, external; eps = FLT_EPSILON], number of matched entries }.
+ * bwd: grad_out[0], [3], [4] are the gradients of out6[0], [3], [4]; d_logit like logit, d_reg like reg (every row written).
+ * The sub-gradients follow torch's: min / max split on ties, clamp(min=0) passes at 0, sign(0) = 0. */
+int vm_instance_loss_fwd(const float* logit, const float* reg, const float* label, const int64_t* match, int n_targets, int n_queries,
+                         float gamma, float alpha, float* out6, void* stream);
+int vm_instance_loss_bwd(const float* logit, const float* reg, const float* label, const int64_t* match, int n_targets, int n_queries,
+                         float gamma, float alpha, const float* out6, const float* grad_out, float* d_logit, float* d_reg, void* stream);
 
 /* Skinny-M linear of the decode step (one row per sample): out[M,N] = x[M,K] W[N,K]^T + alpha2 * x2[M,K2] W2[N,K2]^T
  * + bias[N], then (rounded to bf16) + residual[M,N] — the language-expert nn.Linear calls of

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
     in += (int64_t)begin * ld_in;
     rows_true = min(rows, max(end - begin, 0));
   }
+  const int rows_out = (int)min(ld_out, (int64_t)((rows + 63) / 64) * 64);      // the output's pad columns up to the tile edge are zero-filled
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   for (int i = ty; i < 64; i += 4) {
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
   }
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) out[(int64_t)c * ld_out + r] = tile[tx][i];
+    if (c < cols && r < rows_out) out[(int64_t)c * ld_out + r] = tile[tx][i];      // (zeros beyond the true rows: the K padding)
   }
   if (colsum) {
     __syncthreads();

@@ -747,6 +747,31 @@ def dice_focal(x, target, gamma: float, alpha: float | None):
 
 
 # ----------------------------------------------------------------------------- hyper-network mask product (SAM mask decoder)
+class _InstanceLoss(Function):
+    """the instance losses of one sample in one launch each way (kernels.instance_loss_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, logit, reg, label, match, gamma, alpha):
+        out = K.instance_loss_fwd(logit, reg, label, match, gamma, alpha)
+        ctx.save_for_backward(logit, reg, label, match, out)
+        ctx.gamma, ctx.alpha = gamma, alpha
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logit, reg, label, match, out = ctx.saved_tensors
+        d_logit, d_reg = K.instance_loss_bwd(logit, reg, label, match, ctx.gamma, ctx.alpha, out, g.contiguous())
+        return d_logit, d_reg, None, None, None, None
+
+
+def instance_loss(logit, reg, label, match, gamma: float, alpha: float | None):
+    """logit fp32 [nt, nq], reg fp32 [nt, 1 + nq, 6], label fp32 [n_boxes, 6], match int64 [nt, nq] (matched label box | < 0)
+    -> fp32 [6] = (focal mean over all entries, focal mean matched vs 1 [log], focal mean unmatched vs 0 [log], l1 mean of matched
+    pairs, 1 - mean GIoU of matched pairs, matched count); gradients flow to logit and reg through entries 0, 3, 4"""
+    return _InstanceLoss.apply(logit, reg, label, match, gamma, alpha)
+
+
 class _HyperProduct(Function):
     """y[p] = up[p] @ w[p]^T for every prompt p: up [P, V, C] fp32 (up-scaled image embedding per prompt, channel-last), w [P, M, C]
     (per-prompt hyper-network weights) -> y [P, V, M]. Reference mask_decoder.py:139-147 (`einsum('n m c, n c ... -> n m ...')`).

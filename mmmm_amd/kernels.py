@@ -194,7 +194,7 @@ def transpose(x: torch.Tensor, *, pad_to: int = 1, nrows: torch.Tensor | None = 
     rows, cols = x.shape
     rp = (rows + pad_to - 1) // pad_to * pad_to
     out = torch.empty(cols, rp, dtype=x.dtype, device=x.device)
-    if rp > rows:
+    if rp > (rows + 63) // 64 * 64:      # (up to the next multiple of 64 the kernel zero-fills the pad columns itself)
         out[:, rows:].zero_()
     if colsum_out is not None:
         assert nrows is None and colsum_out.dtype == torch.float32 and colsum_out.is_contiguous() and colsum_out.numel() == cols
@@ -221,7 +221,7 @@ def transpose_segment(x: torch.Tensor, counts: torch.Tensor, segment: int, pad_t
     rows, cols = x.shape
     rp = (rows + pad_to - 1) // pad_to * pad_to
     out = torch.empty(cols, rp, dtype=x.dtype, device=x.device)
-    if rp > rows:
+    if rp > (rows + 63) // 64 * 64:
         out[:, rows:].zero_()
     hip.call('vm_transpose_segment', ptr(x), _ld(x), ptr(out), rp, rows, cols, dtype_code(x.dtype), ptr(counts), segment, stream())
     return out
@@ -622,6 +622,44 @@ def lsap(cost: torch.Tensor, dims: torch.Tensor, max_cols: int) -> torch.Tensor:
     out = torch.full((P, R), -1, dtype=torch.int32, device=cost.device)
     hip.call('vm_lsap_f32', ptr(cost), cost.stride(0), cost.stride(1), ptr(dims), ptr(out), out.stride(0), P, int(max_cols), stream())
     return out
+
+
+def box_match_cost(desc: torch.Tensor, n_problems: int, rows: int, width: int, l1_weight: float, giou_weight: float, disc_weight: float,
+                   match_ce: bool, gamma: float, alpha: float | None) -> torch.Tensor:
+    """desc int64 [P, 6] on the device = {reg ptr, logit ptr, label ptr, n_pos, n_col, nq} per target -> cost fp32 [P, rows, width]"""
+    assert desc.dtype == torch.int64 and desc.is_contiguous() and desc.numel() >= n_problems * 6
+    cost = torch.empty(n_problems, rows, width, dtype=torch.float32, device=desc.device)
+    hip.call('vm_box_match_cost', ptr(desc), n_problems, ptr(cost), rows, width, l1_weight, giou_weight, disc_weight, int(match_ce),
+             gamma, -1.0 if alpha is None else alpha, stream())
+    return cost
+
+
+def _instance_loss_args(logit, reg, label, match):
+    nt, nq = logit.shape
+    assert logit.dtype == torch.float32 and reg.dtype == torch.float32 and label.dtype == torch.float32 and match.dtype == torch.int64
+    assert reg.shape == (nt, nq + 1, 6) and label.dim() == 2 and label.shape[1] == 6 and match.shape == (nt, nq)
+    assert logit.is_contiguous() and reg.is_contiguous() and label.is_contiguous() and match.is_contiguous()
+    return nt, nq
+
+
+def instance_loss_fwd(logit: torch.Tensor, reg: torch.Tensor, label: torch.Tensor, match: torch.Tensor, gamma: float,
+                      alpha: float | None) -> torch.Tensor:
+    """-> fp32 [6]: focal mean (all), focal mean of matched vs 1, of unmatched vs 0, l1 mean, 1 - mean giou, matched count"""
+    nt, nq = _instance_loss_args(logit, reg, label, match)
+    out = torch.empty(6, dtype=torch.float32, device=logit.device)
+    hip.call('vm_instance_loss_fwd', ptr(logit), ptr(reg), ptr(label), ptr(match), nt, nq, gamma, -1.0 if alpha is None else alpha,
+             ptr(out), stream())
+    return out
+
+
+def instance_loss_bwd(logit, reg, label, match, gamma: float, alpha: float | None, out6: torch.Tensor, grad_out: torch.Tensor):
+    """-> (d_logit like logit, d_reg like reg)"""
+    nt, nq = _instance_loss_args(logit, reg, label, match)
+    assert grad_out.dtype == torch.float32 and grad_out.is_contiguous() and grad_out.numel() == 6
+    d_logit, d_reg = torch.empty_like(logit), torch.empty_like(reg)
+    hip.call('vm_instance_loss_bwd', ptr(logit), ptr(reg), ptr(label), ptr(match), nt, nq, gamma, -1.0 if alpha is None else alpha,
+             ptr(out6), ptr(grad_out), ptr(d_logit), ptr(d_reg), stream())
+    return d_logit, d_reg
 
 
 # ------------------------------------------------------------------ generation path

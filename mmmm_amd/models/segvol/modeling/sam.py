@@ -1,10 +1,13 @@
 """Sam / InstanceSam grounding heads and InstanceSamLoss (reference segvol/modeling/sam.py) on the fp32 HIP kernels.
 
 Differences in execution, not in results: the image encoder runs once over the packed batch; the mask decoder works
-channel-last; Hungarian matching stays on the host (scipy, as the reference) but all cost matrices of a sample are
-computed on the device and fetched with ONE device->host copy instead of one per target (reference sam.py:243)."""
+channel-last; on the GPU the Hungarian matching never leaves the device (every cost matrix of the batch from one launch,
+`vm_box_match_cost`; every assignment from one more, `vm_lsap_f32`: SciPy's algorithm, SciPy's result — the reference
+synchronises once per target, sam.py:243) and the instance losses of a sample are one launch each way (`vm_instance_loss_*`).
+CPU tensors take the reference's route (element-wise torch ops, SciPy on the host)."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -140,6 +143,7 @@ class InstanceSamLoss(nn.Module):
         self.box_l1_weight, self.box_giou_weight, self.disc_weight = box_l1_weight, box_giou_weight, disc_weight
         self.disc_focal_gamma, self.disc_focal_alpha = disc_focal_gamma, disc_focal_alpha
         self.match_ce = match_ce
+        self.fused = os.environ.get('VM_INSTANCE_LOSS_FUSED', '1') == '1'      # 0: element-wise torch form on the GPU as well (A/B, tests)
 
     def box_loss(self, input, target, reduce_batch: bool = True, return_dict: bool = False):
         l1 = F.l1_loss(input, target) if reduce_batch else F.l1_loss(input, target, reduction='none').mean(dim=-1)
@@ -211,6 +215,10 @@ class InstanceSamLoss(nn.Module):
         and the match stays on the device: the step has NO device->host synchronisation. (The reference synchronises once per
         target, sam.py:243.) CPU tensors, or a cost matrix wider than the kernel supports, take the reference's route: SciPy
         on the host, one transfer for all samples."""
+        if samples and samples[0][1].is_cuda and self.fused:
+            out = self._match_on_device(samples)
+            if out is not None:
+                return out
         built = []
         for boxes_reg, disc_logit, boxes_label, index_offsets in samples:
             offs = [tuple(x) for x in index_offsets.tolist()]
@@ -229,6 +237,45 @@ class InstanceSamLoss(nn.Module):
             part = [host[k + j][:nq] for j in range(len(costs))] if costs else []
             k += len(costs)
             out.append(self._assign(part, metas, nt, nq))
+        return out
+
+    def _match_on_device(self, samples: list[tuple]) -> list[torch.Tensor] | None:
+        """every cost matrix of every sample from ONE launch (`vm_box_match_cost`), every assignment from one more
+        (`vm_lsap_f32`), the bookkeeping of `_assign` as a few tensor ops; one small metadata upload. None: a matrix is wider than
+        the assignment kernel supports (the caller takes the host route)."""
+        dev = samples[0][1].device
+        nq = samples[0][1].shape[1]
+        assert all(s[1].shape[1] == nq for s in samples)
+        keep, rows_meta, desc, row0, width = [], [], [], 0, 0
+        for boxes_reg, disc_logit, boxes_label, index_offsets in samples:
+            reg, logit, label = boxes_reg.float().contiguous(), disc_logit.float().contiguous(), boxes_label.float().contiguous()
+            keep.append((reg, logit, label))
+            assert reg.shape[1:] == (nq + 1, 6)
+            for i, (s, e) in enumerate(tuple(x) for x in index_offsets.tolist()):
+                npos = e - s
+                if npos > 0:
+                    ncol = max(nq, npos)
+                    width = max(width, ncol)
+                    desc.append((reg.data_ptr() + (i * (nq + 1) + 1) * 24, logit.data_ptr() + i * nq * 4, label.data_ptr() + s * 24,
+                                 npos, ncol, nq))
+                    rows_meta.append((row0 + i, npos, s, nq, ncol, 0))
+            row0 += disc_logit.shape[0]
+        if width > K.LSAP_MAX_COLS:
+            return None
+        match = torch.full((row0, nq), MATCH_NEGATIVE, dtype=torch.int64, device=dev)
+        if desc:
+            n = len(desc)
+            packed = torch.tensor(desc + rows_meta, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+            cost = K.box_match_cost(packed, n, nq, width, self.box_l1_weight, self.box_giou_weight, self.disc_weight, self.match_ce,
+                                    self.disc_focal_gamma, self.disc_focal_alpha)
+            meta = packed[n:]
+            col = K.lsap(cost, meta[:, 3:5].to(torch.int32).contiguous(), width)[:, :nq].long()
+            npos, off = meta[:, 1:2], meta[:, 2:3]
+            match.index_copy_(0, meta[:, 0], torch.where(col >= npos, torch.full_like(col, MATCH_NEGATIVE), col + off))
+        out, row0 = [], 0
+        for _, disc_logit, _, _ in samples:
+            out.append(match[row0:row0 + disc_logit.shape[0]])
+            row0 += disc_logit.shape[0]
         return out
 
     @staticmethod
@@ -264,6 +311,29 @@ class InstanceSamLoss(nn.Module):
     def _match_all(self, boxes_reg_full, disc_logit, boxes_label, index_offsets):
         return self.match_samples([(boxes_reg_full, disc_logit, boxes_label, index_offsets)])[0]
 
+    _weights: dict = {}
+
+    def _compute_loss_fused(self, boxes_reg, disc_logit, boxes_label, index_offsets, match):
+        """the device branch of `compute_loss` as ONE launch each way (`vm_instance_loss_fwd / _bwd`): same terms, same log keys.
+        Which log entries exist depends on how many entries are matched, which is host-known (see compute_loss)."""
+        nt, nq = disc_logit.shape
+        n_pos = sum(min(e - s, nq) for s, e in (tuple(x) for x in index_offsets.tolist()) if e > s)
+        out = Fh.instance_loss(disc_logit.float().contiguous(), boxes_reg.float().contiguous(), boxes_label.float().contiguous(),
+                               match.contiguous(), self.disc_focal_gamma, self.disc_focal_alpha)
+        key = (out.device, self.disc_weight, self.box_l1_weight, self.box_giou_weight)
+        w = self._weights.get(key)
+        if w is None:
+            w = self._weights[key] = torch.tensor([self.disc_weight, 0., 0., self.box_l1_weight, self.box_giou_weight, 0.], device=out.device)
+        loss = torch.dot(out, w)
+        v = out.detach()
+        g = f'focal-{self.disc_focal_gamma:.1f}'
+        log = {f'instance-disc-{g}': v[0]}
+        if n_pos > 0:
+            log.update({f'instance-disc-pos-{g}': v[1], 'instance-box-l1': v[3], 'instance-box-giou': v[4]})
+        if n_pos < nt * nq:
+            log[f'instance-disc-neg-{g}'] = v[2]
+        return loss, log
+
     def compute_loss(self, masks_logits, masks_logits_ds, boxes_reg, disc_logit, masks_label, boxes_label, index_offsets, match=None):
         """reference :252-361, branch used by the training step (no instance masks)"""
         if masks_label is not None:
@@ -275,6 +345,8 @@ class InstanceSamLoss(nn.Module):
         if nt > 0:
             if match is None:
                 match = self._match_all(boxes_reg, disc_logit, boxes_label, index_offsets)      # int64 [nt, nq]
+            if match.is_cuda and self.fused:
+                return self._compute_loss_fused(boxes_reg, disc_logit, boxes_label, index_offsets, match)
             boxes_reg = boxes_reg[:, 1:]
             disc_logit = disc_logit.float()
             dev = disc_logit.device

@@ -237,5 +237,14 @@ def test_device_matching_equals_host_matching_for_every_target_count(dev):
         loss.backward()
         res.append((loss.detach(), {k: v.detach() for k, v in log.items()}, b.grad, d.grad))
     (l0, g0, b0, d0), (l1, g1, b1, d1) = res
-    assert torch.equal(l0, l1) and torch.equal(b0, b1) and torch.equal(d0, d1)
-    assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
+    # (the device assignment takes the fused loss kernels, the host assignment the element-wise torch form: same terms, fp32
+    # sums in a different order)
+    assert rel(l0, l1) < 2e-6 and rel(b0, b1) < 1e-5 and rel(d0, d1) < 1e-5
+    assert g0.keys() == g1.keys() and all(rel(g0[k], g1[k]) < 2e-6 for k in g0)
+    # the element-wise form on the device assignment is bit-identical to the host route
+    il.fused = False
+    b, d = br.clone().requires_grad_(), dl.clone().requires_grad_()
+    loss, log = il.compute_loss(dummy, dummy, b, d, None, boxes_label, index_offsets, match=dev_match)
+    loss.backward()
+    assert torch.equal(loss.detach(), l1) and torch.equal(b.grad, b1) and torch.equal(d.grad, d1)
+    assert all(torch.equal(log[k].detach(), g1[k]) for k in g1)
