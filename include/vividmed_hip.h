@@ -219,6 +219,13 @@ int vm_layernorm_bwd(const void* x, const void* w, const void* dy,
                      const float* mean, const float* rstd,
                      void* dx, float* dw_accum, float* db_accum,
                      int rows, int cols, int dtype, void* stream);
+/* The same with the gradient of the residual branch that forked off x summed in: dx = d norm / dx + dx_add (fp32 sum, ONE rounding to
+ * `dtype`). In a pre-norm block (`h + f(norm(h))`: modeling_cogvlm.py:323-343, segvol image_encoder.py blocks) h feeds the norm and the
+ * residual; autograd would add the two gradients of h with a separate element-wise kernel (three passes over [rows, cols]) per norm. */
+int vm_rmsnorm_bwd_res(const void* x, const void* w, const void* dy, const float* rstd, const void* dx_add,
+                       void* dx, float* dw_accum, int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
+int vm_layernorm_bwd_res(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, const void* dx_add,
+                         void* dx, float* dw_accum, float* db_accum, int rows, int cols, int dtype, void* stream);
 
 /* RoPE, rotate_half form, looked up by explicit position ids —
  * modeling_cogvlm.py:183-193. In place on q and k inside a packed qkv buffer

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_fwd_k(
 template <typename T>
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
-    const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols, const int32_t* nrows_dev) {
+    const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols, const int32_t* nrows_dev,
+    const T* __restrict__ dx_add = nullptr) {      // dx_add: gradient of the residual branch that forked off x, summed in (one rounding)
   constexpr int V = Elem<T>::VEC;
   if (nrows_dev) rows = min(rows, *nrows_dev);
   const int lane = threadIdx.x & 63;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * cols;
   const T* dyr = dy + (int64_t)row * cols;
+  const T* addr = dx_add ? dx_add + (int64_t)row * cols : nullptr;
   T* dxr = dx + (int64_t)row * cols;
   const float r = rstd[row];
   float dot = 0.f;
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
   dot = wave_sum(dot) / (float)cols;
   for (int c = lane * V; c < cols; c += 64 * V) {
     auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c); auto wv = ldv<T>(w + c);
-    typename Elem<T>::vec_t o;
+    typename Elem<T>::vec_t o, av;
+    if (addr) av = ldv<T>(addr + c);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float xh = Elem<T>::ld(xv[i]) * r;
-      o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) - xh * dot));
+      o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[i]) - xh * dot) + (addr ? Elem<T>::ld(av[i]) : 0.f));
     }
     stv<T>(dxr + c, o);
   }
@@ -163,13 +166,15 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_k(
 template <typename T>
 __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_k(
     const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
-    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols) {
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols,
+    const T* __restrict__ dx_add = nullptr) {
   constexpr int V = Elem<T>::VEC;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
   if (row >= rows) return;
   const T* xr = x + (int64_t)row * cols;
   const T* dyr = dy + (int64_t)row * cols;
+  const T* addr = dx_add ? dx_add + (int64_t)row * cols : nullptr;
   T* dxr = dx + (int64_t)row * cols;
   const float mu = mean[row], r = rstd[row];
   float s1 = 0.f, s2 = 0.f;  // sum(w*dy), sum(w*dy*xhat)
@@ -187,12 +192,13 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_k(
   for (int c = lane * V; c < cols; c += 64 * V) {
     auto xv = ldv<T>(xr + c); auto gv = ldv<T>(dyr + c);
     typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
-    typename Elem<T>::vec_t o;
+    typename Elem<T>::vec_t o, av;
+    if (addr) av = ldv<T>(addr + c);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float xh = (Elem<T>::ld(xv[i]) - mu) * r, g = Elem<T>::ld(gv[i]);
       const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
-      o[i] = Elem<T>::st(r * (wg - s1 - xh * s2));
+      o[i] = Elem<T>::st(r * (wg - s1 - xh * s2) + (addr ? Elem<T>::ld(av[i]) : 0.f));
     }
     stv<T>(dxr + c, o);
   }
@@ -705,14 +711,20 @@ int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows,
 
 int vm_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_accum,
                    int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream) {
+  return vm_rmsnorm_bwd_res(x, w, dy, rstd, nullptr, dx, dw_accum, rows, cols, dtype, nrows_dev, stream);
+}
+
+int vm_rmsnorm_bwd_res(const void* x, const void* w, const void* dy, const float* rstd, const void* dx_add, void* dx, float* dw_accum,
+                       int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream) {
   if (rows <= 0) return VM_OK;
+  if (dx_add && !dx) return VM_ERR_BAD_ARG;
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
   DISPATCH_DTYPE(dtype,
                  if (dx) hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                            (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev);
+                                            (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev, (const T*)dx_add);
                  if (dw_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                                   (const T*)dy, (const float*)nullptr, rstd, dw_accum, (float*)nullptr, rows, cols,
                                                   nrows_dev));
@@ -735,14 +747,20 @@ int vm_layernorm_fwd(const void* x, const void* w, const void* b, const void* re
 
 int vm_layernorm_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
                      float* dw_accum, float* db_accum, int rows, int cols, int dtype, void* stream) {
+  return vm_layernorm_bwd_res(x, w, dy, mean, rstd, nullptr, dx, dw_accum, db_accum, rows, cols, dtype, stream);
+}
+
+int vm_layernorm_bwd_res(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, const void* dx_add, void* dx,
+                         float* dw_accum, float* db_accum, int rows, int cols, int dtype, void* stream) {
   if (rows <= 0) return VM_OK;
+  if (dx_add && !dx) return VM_ERR_BAD_ARG;
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
   DISPATCH_DTYPE(dtype,
                  if (dx) hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                            (const T*)dy, mean, rstd, (T*)dx, rows, cols);
+                                            (const T*)dy, mean, rstd, (T*)dx, rows, cols, (const T*)dx_add);
                  if (dw_accum || db_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream,
                                                               (const T*)x, (const T*)dy, mean, rstd, dw_accum, db_accum, rows, cols,
                                                               (const int32_t*)nullptr));

@@ -74,6 +74,9 @@ class LinearMeta:
     f8_1: object = None
     # fp32 operands: arithmetic of this layer's three GEMMs (kernels.gemm `f32_split`; 0 = the process default)
     f32_split: int = 0
+    # also return x itself (a view): a post-norm block's residual takes THAT output, so the residual's gradient arrives in this
+    # node's backward and rides in the dgrad GEMM's epilogue instead of a separate element-wise add over the activations
+    fork: bool = False
 
 
 def _t(w: torch.Tensor) -> torch.Tensor:
@@ -130,6 +133,9 @@ WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
 # read instructions): the step loses more than the freed memory buys (model-hr-3d: every layer kept, yet 3.47 vs 3.59 images/s;
 # phase-vg-448 445 vs 359 ms), so the default stays the NT dgrad on resident transposes.
 NN_DGRAD = os.environ.get('VM_NN_DGRAD', '0') == '1'
+# 0: ops asked to `fork` (hand their input back for the block's residual) return the input itself, i.e. autograd sums the two gradients of
+# the input with its own element-wise add (A/B measurements)
+FORK = os.environ.get('VM_FORK', '1') == '1'
 
 
 def _off_critical_path(fn, device, keep_alive):
@@ -217,6 +223,7 @@ class _Linear(Function):
 
     @staticmethod
     def forward(ctx, meta: LinearMeta, x, residual, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1):
+        x_in = x
         x = x if x.is_contiguous() else x.contiguous()
         lora = meta.lora_scale != 0.0 and A0 is not None
         t = None
@@ -244,13 +251,21 @@ class _Linear(Function):
         ctx.meta, ctx.lora = meta, lora
         ctx.save_for_backward(x, t, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
         ctx.has_residual = residual is not None
+        if meta.fork:
+            ctx.set_materialize_grads(False)
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         meta: LinearMeta = ctx.meta
         x, t, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1 = ctx.saved_tensors
+        if dy is None:                 # only the passed-through input was used downstream
+            return (None, dpass) + (None,) * 12
+        if dpass is not None:
+            dpass = dpass if dpass.dtype == x.dtype else dpass.to(x.dtype)
+            dpass = (dpass if dpass.is_contiguous() else dpass.contiguous()).view(x.shape)
         assert meta.act == hip.ACT_NONE, 'fused activations are forward-only; use the separate activation op when training'
         dy = dy if dy.is_contiguous() else dy.contiguous()
         if dy.dtype != x.dtype:
@@ -273,14 +288,15 @@ class _Linear(Function):
             g[1] = K.gemm_fp8(dy8, sdy, f0.wt8, f0.swt, w1_8=f1.wt8 if gated else None, sw1=f1.swt if gated else None,
                               a2=K.scale_rows(u, inv_dy) if lora else None, b2=K.scale_rows(At0, f0.inv_swt) if lora else None,
                               b2_1=K.scale_rows(At1, f1.inv_swt) if (lora and gated) else None, alpha2=s if lora else 1.0, counts=cnt,
-                              drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed, out_dtype=x.dtype)
+                              drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed, out_dtype=x.dtype, residual=dpass)
         elif need[1] and Wt0 is None and NN_DGRAD and x.dtype == torch.bfloat16 and dy.shape[1] % 64 == 0 and x.shape[1] % 8 == 0:
             # dx = dy W with W as it sits in HBM (the 256-column kernel reads the weight through transposed LDS reads): no transposed
             # copy of the weight, resident or per use
             At0 = (meta.At0 if meta.At0 is not None else _t(A0)) if lora else None
             At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
             g[1] = K.gemm(dy, W0.detach(), w1=W1.detach() if gated else None, b_nn=True, a2=u, b2=At0, b2_1=At1,
-                          alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed)
+                          alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed,
+                          residual=dpass)
         elif need[1]:
             wt0 = Wt0 if Wt0 is not None else K.transpose(W0.detach())
             wt1 = (Wt1 if Wt1 is not None else K.transpose(W1.detach())) if gated else None
@@ -289,7 +305,9 @@ class _Linear(Function):
             At1 = (meta.At1 if meta.At1 is not None else _t(A1)) if (lora and gated) else None
             g[1] = K.gemm(dyp, wt0, w1=wt1, a2=u, b2=At0, b2_1=At1,
                           alpha2=s if lora else 1.0, counts=cnt, drop_p=meta.drop_p if lora else 0.0, drop_seed=meta.drop_seed,
-                          f32_split=meta.f32_split)
+                          f32_split=meta.f32_split, residual=dpass)
+        elif dpass is not None:
+            g[1] = dpass
         if ctx.has_residual and need[2]:
             g[2] = dy
             if WGRAD_SIDE_STREAM and dy.is_cuda:
@@ -399,40 +417,56 @@ def _norm_params_off_path(params, run_kernel, keep_alive):
 
 
 class _RMSNorm(Function):
+    """`fork`: also return x itself (a view) — the residual branch of a pre-norm block takes THAT, so both gradients of x arrive
+    here and the kernel sums them (`dx_add`) instead of autograd adding them with one more pass over the activations"""
+
     @staticmethod
-    def forward(ctx, x, w, eps, nrows):
+    def forward(ctx, x, w, eps, nrows, fork=False):
         y, rstd = K.rmsnorm_fwd(x, w, eps, nrows)
         ctx.save_for_backward(x, w, rstd, nrows)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
+        if dy is None:
+            return dpass, None, None, None, None
         x, w, rstd, nrows = ctx.saved_tensors
+        if dpass is not None and dpass.dtype != x.dtype:
+            dpass = dpass.to(x.dtype)
         if ctx.needs_input_grad[1] and _norm_params_off_path(
                 (w,), lambda dw_out: (K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dx=False, dw_out=dw_out)[1],), (x, dy, rstd, nrows)):
-            return K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=False)[0], None, None, None
-        dx, dw = K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=ctx.needs_input_grad[1])
-        return dx, (dw.to(w.dtype) if dw is not None else None), None, None
+            return K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=False, dx_add=dpass)[0], None, None, None, None
+        dx, dw = K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=ctx.needs_input_grad[1], dx_add=dpass)
+        return dx, (dw.to(w.dtype) if dw is not None else None), None, None, None
 
 
-def rms_norm(x, w, eps: float, nrows=None):
-    return _RMSNorm.apply(x, w, eps, nrows)
+def rms_norm(x, w, eps: float, nrows=None, fork: bool = False):
+    """`fork`: -> (y, x passed through) — use the second output as the block's residual"""
+    if fork and not FORK:
+        return _RMSNorm.apply(x, w, eps, nrows, False), x
+    return _RMSNorm.apply(x, w, eps, nrows, fork)
 
 
 class _LayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, w, b, eps, residual):
+    def forward(ctx, x, w, b, eps, residual, fork=False):
         y, mean, rstd = K.layernorm_fwd(x, w, b, eps, residual)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.has_res = residual is not None
         ctx.bias = b          # only its gradient slot is touched in backward (no value needed): not saved as a tensor
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if fork else y      # (fork: see _RMSNorm)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
+        if dy is None:
+            return dpass, None, None, None, None, None
         x, w, mean, rstd = ctx.saved_tensors
+        if dpass is not None and dpass.dtype != x.dtype:
+            dpass = dpass.to(x.dtype)
         need_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         b = ctx.bias
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and b is not None and _norm_params_off_path(
@@ -440,15 +474,18 @@ class _LayerNorm(Function):
                 (x, dy, mean, rstd)):
             if ctx.has_res and dy.is_cuda and WGRAD_SIDE_STREAM:
                 _hold_until_backward_ends(dy)       # dy doubles as the residual's gradient while the side stream still reads it
-            return K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=False)[0], None, None, None, (dy if ctx.has_res else None)
-        dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=need_dw)
+            return (K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=False, dx_add=dpass)[0], None, None, None,
+                    (dy if ctx.has_res else None), None)
+        dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=need_dw, dx_add=dpass)
         return (dx, dw.to(w.dtype) if dw is not None else None, db.to(w.dtype) if db is not None else None, None,
-                dy if ctx.has_res else None)
+                dy if ctx.has_res else None, None)
 
 
-def layer_norm(x, w, b, eps: float = 1e-5, residual=None):
-    """residual + LayerNorm(x) (residual optional)"""
-    return _LayerNorm.apply(x, w, b, eps, residual)
+def layer_norm(x, w, b, eps: float = 1e-5, residual=None, fork: bool = False):
+    """residual + LayerNorm(x) (residual optional); `fork`: -> (y, x passed through) for a pre-norm block's residual"""
+    if fork and not FORK:
+        return _LayerNorm.apply(x, w, b, eps, residual, False), x
+    return _LayerNorm.apply(x, w, b, eps, residual, fork)
 
 
 # ----------------------------------------------------------------------------- activations

@@ -335,13 +335,18 @@ def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tenso
     return y, rstd
 
 
-def rmsnorm_bwd(x, w, dy, rstd, nrows: torch.Tensor | None = None, need_dw: bool = True, need_dx: bool = True, dw_out=None):
-    """`dw_out`: an fp32 [cols] accumulator to add into (e.g. the parameter's gradient slot) instead of a zeroed scratch"""
+def rmsnorm_bwd(x, w, dy, rstd, nrows: torch.Tensor | None = None, need_dw: bool = True, need_dx: bool = True, dw_out=None, dx_add=None):
+    """`dw_out`: an fp32 [cols] accumulator to add into (e.g. the parameter's gradient slot) instead of a zeroed scratch;
+    `dx_add`: gradient of the residual branch that forked off x, summed into dx by the kernel"""
     x, dy = _c(x), _c(dy)
     rows, cols = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dw = (dw_out if dw_out is not None else torch.zeros(cols, dtype=torch.float32, device=x.device)) if need_dw else None
-    hip.call('vm_rmsnorm_bwd', ptr(x), ptr(w), ptr(dy), ptr(rstd), ptr(dx), ptr(dw), rows, cols, dtype_code(x.dtype), ptr(nrows), stream())
+    if dx_add is not None:
+        dx_add = _c(dx_add)
+        assert need_dx and dx_add.shape == x.shape and dx_add.dtype == x.dtype
+    hip.call('vm_rmsnorm_bwd_res', ptr(x), ptr(w), ptr(dy), ptr(rstd), ptr(dx_add), ptr(dx), ptr(dw), rows, cols, dtype_code(x.dtype),
+             ptr(nrows), stream())
     return dx, dw
 
 
@@ -356,13 +361,16 @@ def layernorm_fwd(x, w, b, eps: float, residual: torch.Tensor | None = None):
     return y, mean, rstd
 
 
-def layernorm_bwd(x, w, dy, mean, rstd, need_dw: bool = True, need_dx: bool = True, dw_out=None, db_out=None):
+def layernorm_bwd(x, w, dy, mean, rstd, need_dw: bool = True, need_dx: bool = True, dw_out=None, db_out=None, dx_add=None):
     x, dy = _c(x), _c(dy)
     rows, cols = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dw = (dw_out if dw_out is not None else torch.zeros(cols, dtype=torch.float32, device=x.device)) if need_dw else None
     db = (db_out if db_out is not None else torch.zeros(cols, dtype=torch.float32, device=x.device)) if need_dw else None
-    hip.call('vm_layernorm_bwd', ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), rows, cols,
+    if dx_add is not None:
+        dx_add = _c(dx_add)
+        assert need_dx and dx_add.shape == x.shape and dx_add.dtype == x.dtype
+    hip.call('vm_layernorm_bwd_res', ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx_add), ptr(dx), ptr(dw), ptr(db), rows, cols,
              dtype_code(x.dtype), stream())
     return dx, dw, db
 

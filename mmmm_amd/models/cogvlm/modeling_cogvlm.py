@@ -39,8 +39,9 @@ class RMSNorm(nn.Module):
         self.weight = NoWeightDecayParameter(torch.ones(hidden_size))      # modeling_cogvlm.py:33
         self.variance_epsilon = eps
 
-    def forward(self, x: torch.Tensor, nrows: torch.Tensor | None = None) -> torch.Tensor:
-        return Fh.rms_norm(x, self.weight, self.variance_epsilon, nrows)
+    def forward(self, x: torch.Tensor, nrows: torch.Tensor | None = None, fork: bool = False):
+        """`fork`: -> (normed, x passed through) — the second output is the pre-norm block's residual (functional._RMSNorm)"""
+        return Fh.rms_norm(x, self.weight, self.variance_epsilon, nrows, fork)
 
 
 class MLP(nn.Module):
@@ -164,8 +165,10 @@ class CogVLMDecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, x: torch.Tensor, rt: Routing) -> torch.Tensor:
-        x = self.self_attn(self.input_layernorm(x, rt.n_rows), rt, residual=x)
-        return self.mlp(self.post_attention_layernorm(x, rt.n_rows), rt.counts, residual=x, decode=rt.kv_lens is not None)
+        h, x = self.input_layernorm(x, rt.n_rows, fork=True)
+        x = self.self_attn(h, rt, residual=x)
+        h, x = self.post_attention_layernorm(x, rt.n_rows, fork=True)
+        return self.mlp(h, rt.counts, residual=x, decode=rt.kv_lens is not None)
 
 
 class PackedHidden:

@@ -90,10 +90,11 @@ class Attention(nn.Module):
         self.query_key_value = Linear(config.hidden_size, config.hidden_size * 3)
         self.dense = Linear(config.hidden_size, config.hidden_size)
 
-    def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
-        qkv = self.query_key_value(x)
+    def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int):
+        """-> (attention output, x passed through the first linear: the block's residual — Linear.forward `fork`)"""
+        qkv, x = self.query_key_value(x, fork=True)
         out = Fh.attention(qkv, cu, max_len, self.num_heads, self.head_dim, self.scale, False)
-        return self.dense(out)
+        return self.dense(out), x
 
 
 class MLP(nn.Module):
@@ -102,8 +103,9 @@ class MLP(nn.Module):
         self.fc1 = Linear(config.hidden_size, config.intermediate_size)
         self.fc2 = Linear(config.intermediate_size, config.hidden_size)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.fc2(Fh.gelu(self.fc1(x)))
+    def forward(self, x: torch.Tensor):
+        h, x = self.fc1(x, fork=True)
+        return self.fc2(Fh.gelu(h)), x
 
 
 class TransformerLayer(nn.Module):
@@ -117,8 +119,12 @@ class TransformerLayer(nn.Module):
 
     def forward(self, x: torch.Tensor, cu: torch.Tensor, max_len: int) -> torch.Tensor:
         ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
-        x = Fh.layer_norm(self.attention(x, cu, max_len), ln1.weight, ln1.bias, ln1.eps, residual=x)
-        return Fh.layer_norm(self.mlp(x), ln2.weight, ln2.bias, ln2.eps, residual=x)
+        # x feeds the branch's first linear AND the residual: the linear hands x back (`fork`) so that the residual's gradient is summed
+        # into the branch's input gradient by the dgrad GEMM's epilogue, not by an element-wise add over [tokens, hidden]
+        a, x = self.attention(x, cu, max_len)
+        x = Fh.layer_norm(a, ln1.weight, ln1.bias, ln1.eps, residual=x)
+        m, x = self.mlp(x)
+        return Fh.layer_norm(m, ln2.weight, ln2.bias, ln2.eps, residual=x)
 
 
 class Transformer(nn.Module):

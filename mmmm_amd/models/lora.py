@@ -180,13 +180,22 @@ class Linear(nn.Module):
                 m.drop_seed = StepState.seed_for(self._site)
         return m
 
-    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None, fork: bool = False):
+        """`fork`: -> (y, x passed through): hand the second output to the block's residual add and the residual's gradient is
+        summed into dx by the dgrad GEMM's epilogue (functional.LinearMeta.fork)"""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         r2 = residual.reshape(-1, self.out_features) if residual is not None else None
         need_dx = torch.is_grad_enabled() and x2.requires_grad
-        y = Fh.linear(x2, self.weight, meta=self.meta(), Wt0=self.wt() if need_dx else None, b0=self.bias, A0=self.A, B0=self.B,
+        meta = self.meta()
+        meta.fork = fork and Fh.FORK
+        y = Fh.linear(x2, self.weight, meta=meta, Wt0=self.wt() if need_dx else None, b0=self.bias, A0=self.A, B0=self.B,
                       residual=r2)
+        if fork and not meta.fork:
+            return y.view(*shape[:-1], self.out_features), x
+        if fork:
+            y, xp = y
+            return y.view(*shape[:-1], self.out_features), xp.view(shape)
         return y.view(*shape[:-1], self.out_features)
 
 

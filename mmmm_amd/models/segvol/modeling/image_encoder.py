@@ -101,9 +101,12 @@ class TransformerBlock(nn.Module):
 
     def forward(self, x, cu, max_len):
         n1, n2 = self.norm1, self.norm2
-        # the residual adds ride in the out_proj / linear2 GEMM epilogues
-        x = self.attn(Fh.layer_norm(x, n1.weight, n1.bias, n1.eps), cu, max_len, residual=x)
-        return self.mlp(Fh.layer_norm(x, n2.weight, n2.bias, n2.eps), residual=x)
+        # the residual adds ride in the out_proj / linear2 GEMM epilogues; their gradients come back through the norms' second output
+        # (`fork`) and are summed into the norm's input gradient by its kernel
+        h, x = Fh.layer_norm(x, n1.weight, n1.bias, n1.eps, fork=True)
+        x = self.attn(h, cu, max_len, residual=x)
+        h, x = Fh.layer_norm(x, n2.weight, n2.bias, n2.eps, fork=True)
+        return self.mlp(h, residual=x)
 
 
 class ImageEncoderViT(nn.Module):

@@ -223,6 +223,10 @@ def test_rmsnorm(dev, K, dt, cols):
     dx, dw = K.rmsnorm_bwd(x.detach(), w.detach(), dy, rstd)
     assert rel_err(dx, xf.grad) < tol
     assert rel_err(dw, wf.grad) < 1e-4
+    # the gradient of a residual branch that forked off x, summed in by the kernel (fp32 sum, one rounding)
+    add = torch.randn(rows, cols, device=dev).to(dt)
+    dx2, _ = K.rmsnorm_bwd(x.detach(), w.detach(), dy, rstd, need_dw=False, dx_add=add)
+    assert rel_err(dx2, xf.grad + add.float()) < tol
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
@@ -245,6 +249,49 @@ def test_layernorm(dev, K, dt, cols):
     dx, dw, db = K.layernorm_bwd(x, w, dy, mean, rstd)
     assert rel_err(dx, xf.grad) < tol
     assert rel_err(dw, wf.grad) < 1e-4 and rel_err(db, bf.grad) < 1e-4
+    dx2, _, _ = K.layernorm_bwd(x, w, dy, mean, rstd, need_dw=False, dx_add=res)
+    assert rel_err(dx2, xf.grad + res.float()) < tol
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_forked_norms_and_linear_sum_the_residual_gradient(dev, K, dt):
+    """`fork`: the op returns its input as a second output; a block uses THAT as its residual, so both gradients of the input reach
+    the op's backward, which sums them in its kernel (norms: dx_add; linear: the dgrad GEMM's residual epilogue). Same result as
+    autograd's own accumulation."""
+    from mmmm_amd import functional as Fh
+    rows, cols = 200, 256
+    tol = 1e-2 if dt == torch.bfloat16 else 1e-5
+    x0 = torch.randn(rows, cols, device=dev).to(dt)
+    w = (1 + 0.1 * torch.randn(cols, device=dev)).to(dt)
+    b = (0.1 * torch.randn(cols, device=dev)).to(dt)
+    W = (torch.randn(cols, cols, device=dev) / 16).to(dt)
+    gy, gp = torch.randn(rows, cols, device=dev).to(dt), torch.randn(rows, cols, device=dev).to(dt)
+
+    def run(op, fork):
+        x = x0.clone().requires_grad_()
+        h = x * 1                                   # a non-leaf input, as inside a model
+        if fork:
+            y, p = op(h, True)
+        else:
+            y, p = op(h, False), h
+        torch.autograd.backward([y, p], [gy, gp])
+        return y.detach(), x.grad
+
+    ops = {
+        'rms': lambda h, f: Fh.rms_norm(h, w, 1e-6, None, f),
+        'ln': lambda h, f: Fh.layer_norm(h, w, b, 1e-6, None, f),
+        'linear': lambda h, f: Fh.linear(h, W, meta=Fh.LinearMeta(fork=f), Wt0=K.transpose(W)),
+    }
+    for name, op in ops.items():
+        y1, g1 = run(op, True)
+        y0, g0 = run(op, False)
+        assert torch.equal(y1, y0), name
+        assert rel_err(g1, g0) < tol, (name, rel_err(g1, g0))
+    # only the passed-through output used downstream: the op's own gradient is absent, the residual's still arrives
+    x = x0.clone().requires_grad_()
+    _, p = Fh.rms_norm(x * 1, w, 1e-6, None, True)
+    p.backward(gp)
+    assert torch.equal(x.grad, gp)
 
 
 # ------------------------------------------------------------------ rope
