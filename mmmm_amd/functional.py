@@ -136,6 +136,10 @@ NN_DGRAD = os.environ.get('VM_NN_DGRAD', '0') == '1'
 # 0: ops asked to `fork` (hand their input back for the block's residual) return the input itself, i.e. autograd sums the two gradients of
 # the input with its own element-wise add (A/B measurements)
 FORK = os.environ.get('VM_FORK', '1') == '1'
+# the LINEAR form of the fork (post-norm ViT-E blocks: the residual's gradient rides in the dgrad GEMM's epilogue) is off by default: it
+# removes 126 element-wise adds per step but makes 126 dgrad GEMMs read one more [tokens, hidden] operand — step time equal
+# (342.4 vs 342.8 ms), dominant-GEMM rate 1 164 vs 1 178 TFLOP/s (A B A B in one call). VM_FORK_LINEAR=1 turns it on.
+FORK_LINEAR = FORK and os.environ.get('VM_FORK_LINEAR', '0') == '1'
 
 
 def _off_critical_path(fn, device, keep_alive):

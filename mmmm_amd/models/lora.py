@@ -188,7 +188,7 @@ class Linear(nn.Module):
         r2 = residual.reshape(-1, self.out_features) if residual is not None else None
         need_dx = torch.is_grad_enabled() and x2.requires_grad
         meta = self.meta()
-        meta.fork = fork and Fh.FORK
+        meta.fork = fork and Fh.FORK_LINEAR
         y = Fh.linear(x2, self.weight, meta=meta, Wt0=self.wt() if need_dx else None, b0=self.bias, A0=self.A, B0=self.B,
                       residual=r2)
         if fork and not meta.fork:

@@ -72,6 +72,16 @@ int main() {
   EXPECT(vm_tn_skinny_bf16(nullptr, 0, 64, nullptr, 0, nullptr, nullptr, 0, VM_BF16, 0, 0, 8, nullptr, -1, nullptr, 1.f, 0.f, 0, nullptr, 0, nullptr),
          VM_ERR_BAD_ARG);
 
+  // instance losses / matching costs / forked norms [r2]
+  EXPECT(vm_box_match_cost(nullptr, 3, f, 6, 8, 5.f, 2.f, 2.f, 1, 2.f, 0.85f, nullptr), VM_ERR_BAD_ARG);
+  EXPECT(vm_box_match_cost(nullptr, 0, f, 6, 8, 5.f, 2.f, 2.f, 1, 2.f, 0.85f, nullptr), VM_OK);               // no problems: nothing to do
+  EXPECT(vm_instance_loss_fwd(f, f, f, nullptr, 2, 3, 2.f, 0.85f, f, nullptr), VM_ERR_BAD_ARG);                // no assignment
+  EXPECT(vm_instance_loss_fwd(f, f, f, reinterpret_cast<const int64_t*>(p), 0, 3, 2.f, 0.85f, f, nullptr), VM_OK);
+  EXPECT(vm_instance_loss_bwd(f, f, f, reinterpret_cast<const int64_t*>(p), 2, 3, 2.f, 0.85f, f, nullptr, f, f, nullptr), VM_ERR_BAD_ARG);
+  EXPECT(vm_rmsnorm_bwd_res(p, p, p, f, p, nullptr, nullptr, 4, 64, VM_BF16, nullptr, nullptr), VM_ERR_BAD_ARG);   // residual gradient without dx
+  EXPECT(vm_layernorm_bwd_res(p, p, p, f, f, p, nullptr, nullptr, nullptr, 4, 64, VM_F32, nullptr), VM_ERR_BAD_ARG);
+  EXPECT(vm_rmsnorm_bwd_res(p, p, p, f, nullptr, p, nullptr, 4, 60, VM_BF16, nullptr, nullptr), VM_ERR_BAD_ARG);    // cols % 8
+
   // event-profiling bookkeeping (no events are created while the mask is 0)
   EXPECT(vm_prof_enable(0), VM_OK);
   EXPECT(vm_prof_stride(0), VM_ERR_BAD_ARG);

@@ -294,6 +294,33 @@ def test_forked_norms_and_linear_sum_the_residual_gradient(dev, K, dt):
     assert torch.equal(x.grad, gp)
 
 
+def test_vit_layer_with_the_linear_fork_matches_the_default(dev, K, monkeypatch):
+    """VM_FORK_LINEAR (off by default): a post-norm ViT-E layer whose residual gradients ride in the dgrad GEMM epilogues gives the
+    same output and, up to one bf16 rounding per sum, the same gradients as the default (autograd's own adds)"""
+    from argparse import Namespace
+    from mmmm_amd import functional as Fh
+    from mmmm_amd.models.cogvlm.visual import TransformerLayer
+    torch.manual_seed(5)
+    cfg = Namespace(hidden_size=256, num_heads=4, intermediate_size=512, layer_norm_eps=1e-6)
+    layer = TransformerLayer(cfg).to(dev).bfloat16()
+    x0 = torch.randn(2 * 65, 256, device=dev).bfloat16()
+    cu = Fh.cu_seqlens_tensor([65, 65], dev)
+    gy = torch.randn_like(x0)
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(Fh, 'FORK_LINEAR', on)
+        layer.zero_grad()
+        x = x0.clone().requires_grad_()
+        y = layer(x * 1, cu, 65)
+        y.backward(gy)
+        res.append((y.detach(), x.grad, {n: p.grad.clone() for n, p in layer.named_parameters()}))
+    (y0, g0, p0), (y1, g1, p1) = res
+    assert torch.equal(y0, y1)
+    assert rel_err(g1, g0) < 1e-2
+    for n in p0:
+        assert rel_err(p1[n], p0[n]) < 2e-2, n
+
+
 # ------------------------------------------------------------------ rope
 def _rope_ref(q, k, cos, sin, pos):
     def rot(x):

@@ -66,10 +66,11 @@ for rep in range(2):
     t0 = time.perf_counter()
     e0.record(main)
     step()
+    step()                     # two steps back to back: does the host's lead survive the step boundary?
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f'rep {rep}: host enqueue {1e3 * (t1 - t0):.1f} ms, GPU done {1e3 * (t2 - t0):.1f} ms, {count[0]} native launches')
+    print(f'rep {rep}: 2 steps: host enqueue {1e3 * (t1 - t0):.1f} ms, GPU done {1e3 * (t2 - t0):.1f} ms, {count[0]} native launches')
 rows = [(1e3 * (t - t0), e0.elapsed_time(ev), name, ph, n) for t, ev, name, ph, n in marks]
 print('launch#  phase      host ms   gpu ms   lead ms  kernel')
 prev = None
