@@ -458,6 +458,9 @@ typedef struct vm_attn_f32_args {
   const float* dout; int64_t do_bs, do_ls;
   float* dq; float* dk; float* dv;           /* same strides as q/k/v */
   float* delta;
+  int32_t f32_split;       /* arithmetic of the four products (head_dim 64 only; other head dims always take the exact form):
+                              0 / 1 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 2 = split-bf16 with 3 products (~2^-17 per product),
+                              3 = split-bf16 with 6 products (fp32 products) on v_mfma_f32_32x32x16_bf16 — cf. vm_gemm_args.f32_split */
 } vm_attn_f32_args;
 int vm_attn_fwd_f32(const vm_attn_f32_args* args_host, void* stream);
 int vm_attn_bwd_f32(const vm_attn_f32_args* args_host, void* stream);

@@ -19,6 +19,63 @@ constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- split-bf16 products (NS = 2: 3 MFMAs, ~2^-17 per product; NS = 3: 6 MFMAs, fp32 products) on v_mfma_f32_32x32x16_bf16, same
+// accumulator layout as v_mfma_f32_32x32x2_f32: lane (i = lane & 31, h = lane >> 5) supplies 8 consecutive k = 8 h + 0..7 of a 16-long
+// k-step where the f32 instruction takes one k = h of a 2-long step. An fp32 operand x is split in registers into bf16 terms
+// x = t0 + t1 (+ t2) (each subtraction exact) and the product summed from the leading cross terms, smallest first (gemm.hip, split_f32x8).
+template <int NS>
+__device__ __forceinline__ void split8(const float (&x0)[8], bf16x8_t (&t)[NS]) {
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = x0[e];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    bf16x8_t hh;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hh[e] = (__bf16)x[e];
+    t[s] = hh;
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] -= (float)hh[e];
+    }
+  }
+}
+template <int NS>
+__device__ __forceinline__ f32x16_t mma_split(const bf16x8_t (&a)[NS], const bf16x8_t (&b)[NS], f32x16_t acc) {
+#pragma unroll
+  for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+    for (int sw = 0; sw <= d; ++sw) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sw], b[d - sw], acc, 0, 0, 0);
+  return acc;
+}
+// A-operand fragment of a k-step out of an fp32 LDS tile: 8 floats at `base + i * stride`, split
+template <int NS>
+__device__ __forceinline__ void lds_frag(const float* base, int stride, bf16x8_t (&t)[NS]) {
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = base[i * stride];
+  split8<NS>(x, t);
+}
+// B-operand fragment out of 8 accumulator registers acc[8 j .. 8 j + 7] (k = 8 h + i <-> row acc_row(8 j + i, h) of the tile)
+template <int NS>
+__device__ __forceinline__ void acc_frag(const f32x16_t& a, int j, bf16x8_t (&t)[NS]) {
+  float x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = a[8 * j + i];
+  split8<NS>(x, t);
+}
+// a lane's row operand (q, dO, k, v: HD floats of row `row`, this lane's half h of every 16-long k-step), split once per kernel
+template <int HD, int NS>
+__device__ __forceinline__ void row_frags(const float* row, bool valid, int h, bf16x8_t (&t)[HD / 16][NS]) {
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = valid ? row[16 * s + 8 * h + i] : 0.f;
+    split8<NS>(x, t[s]);
+  }
+}
+
 struct AP {
   const float* q; const float* k; const float* v; float* out;
   int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;
@@ -71,8 +128,9 @@ __device__ __forceinline__ void stage(const float* base, int64_t ls, int head, i
 }
 
 // ----------------------------------------------------------------------------- forward
-template <int HD>
+template <int HD, int NS = 0>
 __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
+  constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;            // k-steps of the 32x32x2 MFMA over the head dimension
@@ -87,9 +145,14 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
   const int qpos = q0 + wave * 32 + (lane & 31);
   const bool qvalid = qpos < sq.lq;
   const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
-  float qf[KS];
+  float qf[NS > 0 ? 1 : KS];
+  bf16x8_t qs[KB][NSS];
+  if constexpr (NS > 0) {
+    row_frags<HD, NS>(qrow, qvalid, h, qs);
+  } else {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) qf[s] = qvalid ? qrow[2 * s + h] : 0.f;
+    for (int s = 0; s < KS; ++s) qf[s] = qvalid ? qrow[2 * s + h] : 0.f;
+  }
 
   f32x16_t o[NB];
 #pragma unroll
@@ -108,9 +171,18 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
     f32x16_t sa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+    if constexpr (NS > 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
+      for (int s = 0; s < KB; ++s) {
+        bf16x8_t ka[NSS];
+        lds_frag<NSS>(sK + (lane & 31) * PITCH + 16 * s + 8 * h, 1, ka);
+        sa = mma_split<NSS>(ka, qs[s], sa);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
+    }
     float mx = NEG_BIG;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -133,9 +205,28 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+    }
+    if constexpr (NS > 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], o[b], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        bf16x8_t pb[NSS];
+        acc_frag<NSS>(sa, j, pb);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] = sV[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
+          bf16x8_t va[NSS];
+          split8<NSS>(x, va);
+          o[b] = mma_split<NSS>(va, pb, o[b]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], o[b], 0, 0, 0);
     }
   }
   if (!qvalid) return;
@@ -169,8 +260,9 @@ __global__ __launch_bounds__(256) void attn_f32_delta_k(const AP p) {
 }
 
 // ----------------------------------------------------------------------------- backward dQ
-template <int HD>
+template <int HD, int NS = 0>
 __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
+  constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;
@@ -186,9 +278,15 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
   const bool qvalid = qpos < sq.lq;
   const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
   const float* dorow = p.dout + sq.doo + (int64_t)(qvalid ? qpos : 0) * p.do_ls + head * HD;
-  float qf[KS], dof[KS];
+  float qf[NS > 0 ? 1 : KS], dof[NS > 0 ? 1 : KS];
+  bf16x8_t qs[KB][NSS], dos[KB][NSS];
+  if constexpr (NS > 0) {
+    row_frags<HD, NS>(qrow, qvalid, h, qs);
+    row_frags<HD, NS>(dorow, qvalid, h, dos);
+  } else {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) { qf[s] = qvalid ? qrow[2 * s + h] : 0.f; dof[s] = qvalid ? dorow[2 * s + h] : 0.f; }
+    for (int s = 0; s < KS; ++s) { qf[s] = qvalid ? qrow[2 * s + h] : 0.f; dof[s] = qvalid ? dorow[2 * s + h] : 0.f; }
+  }
   const float lse2 = qvalid ? p.lse[stat_idx(p, head, sq.stat0, qpos)] * LOG2E : 0.f;
   const float dlt = qvalid ? p.delta[stat_idx(p, head, sq.stat0, qpos)] : 0.f;
   const float sc = p.scale * LOG2E;
@@ -207,10 +305,21 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
     f32x16_t sa, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+    if constexpr (NS > 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * PITCH + 2 * s + h], dof[s], dp, 0, 0, 0);
+      for (int s = 0; s < KB; ++s) {
+        bf16x8_t ka[NSS], va[NSS];
+        lds_frag<NSS>(sK + (lane & 31) * PITCH + 16 * s + 8 * h, 1, ka);
+        lds_frag<NSS>(sV + (lane & 31) * PITCH + 16 * s + 8 * h, 1, va);
+        sa = mma_split<NSS>(ka, qs[s], sa);
+        dp = mma_split<NSS>(va, dos[s], dp);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * PITCH + 2 * s + h], dof[s], dp, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -218,11 +327,28 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
       const float pr = (kvpos < sq.lk && qvalid) ? exp2f(sa[r] * sc - lse2) : 0.f;
       sa[r] = pr * (dp[r] - dlt) * p.scale;
     }
+    if constexpr (NS > 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+      for (int j = 0; j < 2; ++j) {
+        bf16x8_t sb[NSS];
+        acc_frag<NSS>(sa, j, sb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        dq[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dq[b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) {
+          float x[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] = sK[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
+          bf16x8_t ka[NSS];
+          split8<NSS>(x, ka);
+          dq[b] = mma_split<NSS>(ka, sb, dq[b]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dq[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dq[b], 0, 0, 0);
+    }
   }
   if (!qvalid) return;
   float* drow = p.dq + sq.qo + (int64_t)qpos * p.q_ls + head * HD;
@@ -236,8 +362,9 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
 }
 
 // ----------------------------------------------------------------------------- backward dK, dV
-template <int HD>
+template <int HD, int NS = 0>
 __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
+  constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;
@@ -255,9 +382,15 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
   const bool kvalid = kpos < sq.lk;
   const float* krow = p.k + sq.ko + (int64_t)(kvalid ? kpos : 0) * p.k_ls + head * HD;
   const float* vrow = p.v + sq.vo + (int64_t)(kvalid ? kpos : 0) * p.v_ls + head * HD;
-  float kf[KS], vf[KS];
+  float kf[NS > 0 ? 1 : KS], vf[NS > 0 ? 1 : KS];
+  bf16x8_t ks[KB][NSS], vs[KB][NSS];
+  if constexpr (NS > 0) {
+    row_frags<HD, NS>(krow, kvalid, h, ks);
+    row_frags<HD, NS>(vrow, kvalid, h, vs);
+  } else {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) { kf[s] = kvalid ? krow[2 * s + h] : 0.f; vf[s] = kvalid ? vrow[2 * s + h] : 0.f; }
+    for (int s = 0; s < KS; ++s) { kf[s] = kvalid ? krow[2 * s + h] : 0.f; vf[s] = kvalid ? vrow[2 * s + h] : 0.f; }
+  }
   const float sc = p.scale * LOG2E;
   f32x16_t dk[NB], dv[NB];
 #pragma unroll
@@ -279,10 +412,21 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
     f32x16_t sa, dp, pa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+    if constexpr (NS > 0) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[(lane & 31) * PITCH + 2 * s + h], kf[s], sa, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[(lane & 31) * PITCH + 2 * s + h], vf[s], dp, 0, 0, 0);
+      for (int s = 0; s < KB; ++s) {
+        bf16x8_t qa[NSS], da[NSS];
+        lds_frag<NSS>(sQ + (lane & 31) * PITCH + 16 * s + 8 * h, 1, qa);
+        lds_frag<NSS>(sDO + (lane & 31) * PITCH + 16 * s + 8 * h, 1, da);
+        sa = mma_split<NSS>(qa, ks[s], sa);
+        dp = mma_split<NSS>(da, vs[s], dp);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[(lane & 31) * PITCH + 2 * s + h], kf[s], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[(lane & 31) * PITCH + 2 * s + h], vf[s], dp, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -292,13 +436,36 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
       pa[r] = pr;
       sa[r] = pr * (dp[r] - sDlt[qi]) * p.scale;
     }
+    if constexpr (NS > 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+      for (int j = 0; j < 2; ++j) {
+        bf16x8_t pb[NSS], sb[NSS];
+        acc_frag<NSS>(pa, j, pb);
+        acc_frag<NSS>(sa, j, sb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dv[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], pa[r], dv[b], 0, 0, 0);
-        dk[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dk[b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) {
+          float x[8], y[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            x[i] = sDO[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
+            y[i] = sQ[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
+          }
+          bf16x8_t da[NSS], qa[NSS];
+          split8<NSS>(x, da);
+          split8<NSS>(y, qa);
+          dv[b] = mma_split<NSS>(da, pb, dv[b]);
+          dk[b] = mma_split<NSS>(qa, sb, dk[b]);
+        }
       }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dv[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sDO[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], pa[r], dv[b], 0, 0, 0);
+          dk[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[acc_row(r, h) * PITCH + 32 * b + (lane & 31)], sa[r], dk[b], 0, 0, 0);
+        }
+    }
   }
   if (!kvalid) return;
   float* dkrow = p.dk + sq.ko + (int64_t)kpos * p.k_ls + head * HD;
@@ -357,7 +524,14 @@ int vm_attn_fwd_f32(const vm_attn_f32_args* a, void* stream) {
   dim3 grid((a->Lq + 127) / 128, a->n_heads, p.Bn);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  F32_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_f32_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  // f32_split (head_dim 64, the SAM ViT-B encoders): the products on split-bf16 MFMAs instead of the exact f32 MFMA chain
+  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
+  if (a->f32_split >= 2 && a->head_dim == 64) {
+    if (a->f32_split == 2) hipLaunchKernelGGL((attn_f32_fwd_k<64, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_f32_fwd_k<64, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  } else {
+    F32_DISPATCH_HD(a->head_dim, hipLaunchKernelGGL(attn_f32_fwd_k<HD>, grid, dim3(256), 0, (hipStream_t)stream, p));
+  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, 4.0 * a->Lq * (double)a->Lk * a->head_dim * a->n_heads * p.Bn);
   VM_LAUNCH_CHECK();
   return VM_OK;
@@ -371,10 +545,22 @@ int vm_attn_bwd_f32(const vm_attn_f32_args* a, void* stream) {
   dim3 gd((a->Lq + 3) / 4, a->n_heads, p.Bn);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  F32_DISPATCH_HD(a->head_dim,
-                  hipLaunchKernelGGL(attn_f32_delta_k<HD>, gd, dim3(256), 0, (hipStream_t)stream, p);
-                  hipLaunchKernelGGL(attn_f32_dq_k<HD>, gq, dim3(256), 0, (hipStream_t)stream, p);
-                  hipLaunchKernelGGL(attn_f32_dkv_k<HD>, gk, dim3(256), 0, (hipStream_t)stream, p));
+  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
+  if (a->f32_split >= 2 && a->head_dim == 64) {
+    hipLaunchKernelGGL(attn_f32_delta_k<64>, gd, dim3(256), 0, (hipStream_t)stream, p);
+    if (a->f32_split == 2) {
+      hipLaunchKernelGGL((attn_f32_dq_k<64, 2>), gq, dim3(256), 0, (hipStream_t)stream, p);
+      hipLaunchKernelGGL((attn_f32_dkv_k<64, 2>), gk, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+      hipLaunchKernelGGL((attn_f32_dq_k<64, 3>), gq, dim3(256), 0, (hipStream_t)stream, p);
+      hipLaunchKernelGGL((attn_f32_dkv_k<64, 3>), gk, dim3(256), 0, (hipStream_t)stream, p);
+    }
+  } else {
+    F32_DISPATCH_HD(a->head_dim,
+                    hipLaunchKernelGGL(attn_f32_delta_k<HD>, gd, dim3(256), 0, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL(attn_f32_dq_k<HD>, gq, dim3(256), 0, (hipStream_t)stream, p);
+                    hipLaunchKernelGGL(attn_f32_dkv_k<HD>, gk, dim3(256), 0, (hipStream_t)stream, p));
+  }
   vm_prof_end_(VM_PROF_ATTN, stream, tok, 10.0 * a->Lq * (double)a->Lk * a->head_dim * a->n_heads * p.Bn);
   VM_LAUNCH_CHECK();
   return VM_OK;

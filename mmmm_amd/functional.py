@@ -622,28 +622,31 @@ class _SelfAttentionF32(Function):
     both directions and the gradient is ONE dqkv tensor written in place by the kernels — no contiguous copies of the
     thirds, no zero-filled slice gradients, no accumulation adds."""
     @staticmethod
-    def forward(ctx, qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen):
+    def forward(ctx, qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split=0):
         Cw = n_heads * head_dim
         qkv = qkv if qkv.stride(-1) == 1 else qkv.contiguous()
-        out, lse = K.attn_f32_fwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+        out, lse = K.attn_f32_fwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], n_heads, head_dim, scale, cu_seqlens, max_seqlen,
+                                  f32_split=f32_split)
         ctx.save_for_backward(qkv, out, lse, cu_seqlens)
-        ctx.cfg = (n_heads, head_dim, scale, max_seqlen)
+        ctx.cfg = (n_heads, head_dim, scale, max_seqlen, f32_split)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         qkv, out, lse, cu = ctx.saved_tensors
-        n_heads, head_dim, scale, max_seqlen = ctx.cfg
+        n_heads, head_dim, scale, max_seqlen, f32_split = ctx.cfg
         Cw = n_heads * head_dim
         dqkv = torch.empty_like(qkv)      # every row belongs to a sequence: the dq / dkv kernels write all of it
         K.attn_f32_bwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], out, lse, dout, n_heads, head_dim, scale, cu, max_seqlen,
-                       grads=(dqkv[:, :Cw], dqkv[:, Cw:2 * Cw], dqkv[:, 2 * Cw:]))
-        return dqkv, None, None, None, None, None
+                       grads=(dqkv[:, :Cw], dqkv[:, Cw:2 * Cw], dqkv[:, 2 * Cw:]), f32_split=f32_split)
+        return dqkv, None, None, None, None, None, None
 
 
-def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen):
-    return _SelfAttentionF32.apply(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen, f32_split: int = 0):
+    """`f32_split` (head_dim 64): arithmetic of the attention products — 0 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products
+    (kernels.attn_f32_fwd); the image encoders pass their blocks' `f32_split` (image_encoder.ENCODER_F32_SPLIT)"""
+    return _SelfAttentionF32.apply(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split)
 
 
 _F32_HEAD_DIMS = (8, 16, 32, 48, 64, 96, 128)       # instantiations of attn_f32_*_k (csrc/attn_f32.hip)

@@ -79,6 +79,7 @@ class AttnF32Args(C.Structure):
         ('dout', C.c_void_p), ('do_bs', C.c_int64), ('do_ls', C.c_int64),
         ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p),
         ('delta', C.c_void_p),
+        ('f32_split', C.c_int32),
     ]
 
 

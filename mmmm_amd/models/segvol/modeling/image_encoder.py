@@ -16,6 +16,8 @@ from ...lora import Linear
 from ...resample import Downsample, resample
 
 ENCODER_F32_SPLIT = int(os.environ.get('VM_ENC_F32_SPLIT', '2'))
+# arithmetic of the blocks' attention products (functional.self_attention_f32): -1 = the same as the blocks' GEMMs
+ATTN_F32_SPLIT = int(os.environ.get('VM_ATTN_F32_SPLIT', '-1'))
 
 
 class PatchEmbeddingBlock(nn.Module):
@@ -77,7 +79,8 @@ class SABlock(nn.Module):
         self.qkv = Linear(hidden_size, hidden_size * 3, bias=qkv_bias)
 
     def forward(self, x, cu, max_len, residual=None):
-        out = Fh.self_attention_f32(self.qkv(x), self.num_heads, self.head_dim, self.scale, cu, max_len)
+        split = ATTN_F32_SPLIT if ATTN_F32_SPLIT >= 0 else self.qkv.f32_split
+        out = Fh.self_attention_f32(self.qkv(x), self.num_heads, self.head_dim, self.scale, cu, max_len, f32_split=split)
         return self.out_proj(out, residual=residual)
 
 

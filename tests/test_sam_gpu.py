@@ -46,6 +46,41 @@ def test_attention_f32_varlen(dev):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize('split,tol', [(2, 3e-5), (3, 3e-6)])
+@pytest.mark.parametrize('lens', [[784, 784, 784, 784], [8, 16, 17, 130, 2048]])
+def test_attention_f32_split_products(dev, split, tol, lens):
+    """head_dim 64 (SAM ViT-B) with the four products of attention on split-bf16 MFMAs (`f32_split` 2: three products, ~2^-17 each;
+    3: six products = fp32 products) against an fp64 reference, forward and all three gradients, packed var-len; and the exact
+    form's error on the same problem for scale (the bound is relative to the largest magnitude, as everywhere in this file)"""
+    from mmmm_amd import kernels as K
+    H, hd = 12, 64
+    T, C = sum(lens), H * hd
+    torch.manual_seed(11)
+    qkv = torch.randn(T, 3 * C, device=dev)
+    qkv[:, :2 * C] *= 1.5                                     # scores with a spread of a few units, like trained attention
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    dout = torch.randn(T, C, device=dev)
+    x = qkv.double().requires_grad_()
+    ref = torch.zeros(T, C, dtype=torch.float64, device=dev)
+    s = 0
+    outs = []
+    for n in lens:
+        q, k, v = (x[s:s + n, i * C:(i + 1) * C].view(n, H, hd).transpose(0, 1) for i in range(3))
+        outs.append(((q @ k.transpose(1, 2) * hd ** -0.5).softmax(-1) @ v).transpose(0, 1).reshape(n, C))
+        s += n
+    ref = torch.cat(outs)
+    ref.backward(dout.double())
+    res = {}
+    for mode in (0, split):
+        out, lse = K.attn_f32_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], H, hd, hd ** -0.5, cu, max(lens), f32_split=mode)
+        dqkv = torch.empty_like(qkv)
+        K.attn_f32_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, lse, dout, H, hd, hd ** -0.5, cu, max(lens),
+                       grads=(dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]), f32_split=mode)
+        res[mode] = (rel(out, ref), rel(dqkv[:, :C], x.grad[:, :C]), rel(dqkv[:, C:2 * C], x.grad[:, C:2 * C]), rel(dqkv[:, 2 * C:], x.grad[:, 2 * C:]))
+    assert max(res[0]) < 3e-6, res
+    assert max(res[split]) < tol, res
+
+
 def _tiny_sams(dev):
     from mmmm_amd.models import build_instance_sam, build_sam
     sam = build_sam(embed_dim=128, encoder_num_layers=2, num_heads=2, patch_size=(4, 8, 8), pos_embed_shape=(2, 2, 4))
