@@ -64,6 +64,72 @@ __device__ __forceinline__ void acc_frag(const f32x16_t& a, int j, bf16x8_t (&t)
   for (int i = 0; i < 8; ++i) x[i] = a[8 * j + i];
   split8<NS>(x, t);
 }
+// ---- split path, LDS side: a 32-row tile of an fp32 operand is split ONCE, by the threads that stage it, into NS bf16 planes, in the
+// layouts the MFMA operands are read in (instead of every wave splitting every fragment it reads out of an fp32 tile):
+//   row-major planes  [NS][32][PK]   (PK = HD + 8 bf16: 16-byte aligned rows, 144 B for HD 64): fragment = one ds_read_b128
+//   transposed planes [NS][HD][PV]   (PV = 36 bf16: 8-byte aligned rows): a k-step's 8 tile rows are acc_row(8 j + i, h) = two runs of
+//                                    four consecutive rows 16 j + 4 h + {0..3} and + 8: fragment = two ds_read_b64
+constexpr int PV = 36;
+// Two halves, so that the global loads of tile t + 1 are in flight while tile t is computed: tile_load (global -> registers, HD / 32
+// float4 per thread) and tile_store (registers -> split -> LDS planes).
+template <int HD>
+__device__ __forceinline__ void tile_load(const float* base, int64_t ls, int head, int pos0, int len, f32x4_t (&v)[HD / 32], int tid) {
+  constexpr int PER_ROW = HD / 4;
+#pragma unroll
+  for (int it = 0; it < HD / 32; ++it) {
+    const int c = tid + it * 256;
+    const int row = c / PER_ROW, ch = c % PER_ROW;
+    const int pos = pos0 + row;
+    v[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (pos < len) v[it] = *reinterpret_cast<const f32x4_t*>(base + (int64_t)pos * ls + head * HD + ch * 4);
+  }
+}
+template <int HD, int NS, bool ROWM, bool TRANS>
+__device__ __forceinline__ void tile_store(const f32x4_t (&v)[HD / 32], unsigned short* rowm, unsigned short* trans, int tid) {
+  constexpr int PK = HD + 8, PER_ROW = HD / 4;
+#pragma unroll
+  for (int it = 0; it < HD / 32; ++it) {
+    const int c = tid + it * 256;
+    const int row = c / PER_ROW, ch = c % PER_ROW;
+    float x[4] = {v[it][0], v[it][1], v[it][2], v[it][3]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      u16x4_t t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 b = (__bf16)x[e];
+        t[e] = __builtin_bit_cast(unsigned short, b);
+        if (s + 1 < NS) x[e] -= (float)b;
+      }
+      if (ROWM) *reinterpret_cast<u16x4_t*>(rowm + s * 32 * PK + row * PK + ch * 4) = t;
+      if (TRANS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) trans[s * HD * PV + (ch * 4 + e) * PV + row] = t[e];
+      }
+    }
+  }
+}
+// A fragment out of the row-major planes: row `row`, elements col0 .. col0 + 7
+template <int HD, int NS>
+__device__ __forceinline__ void rowm_frag(const unsigned short* rowm, int row, int col0, bf16x8_t (&t)[NS]) {
+  constexpr int PK = HD + 8;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) t[s] = *reinterpret_cast<const bf16x8_t*>(rowm + s * 32 * PK + row * PK + col0);
+}
+// A fragment out of the transposed planes: plane row `d` (a head-dim index), the k-step j's tile rows acc_row(8 j + i, h)
+template <int HD, int NS>
+__device__ __forceinline__ void trans_frag(const unsigned short* trans, int d, int j, int h, bf16x8_t (&t)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const unsigned short* r = trans + s * HD * PV + d * PV + 16 * j + 4 * h;
+    const u16x4_t lo = *reinterpret_cast<const u16x4_t*>(r), hi = *reinterpret_cast<const u16x4_t*>(r + 8);
+    const u16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    t[s] = __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+constexpr int rowm_elems(int hd, int ns) { return ns * 32 * (hd + 8); }
+constexpr int trans_elems(int hd, int ns) { return ns * hd * PV; }
+
 // a lane's row operand (q, dO, k, v: HD floats of row `row`, this lane's half h of every 16-long k-step), split once per kernel
 template <int HD, int NS>
 __device__ __forceinline__ void row_frags(const float* row, bool valid, int h, bf16x8_t (&t)[HD / 16][NS]) {
@@ -129,14 +195,20 @@ __device__ __forceinline__ void stage(const float* base, int64_t ls, int head, i
 
 // ----------------------------------------------------------------------------- forward
 template <int HD, int NS = 0>
-__global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
+__global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP p) {
   constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;            // k-steps of the 32x32x2 MFMA over the head dimension
   constexpr int PITCH = HDP + 1;
-  __shared__ float sK[32 * PITCH];
-  __shared__ float sV[32 * PITCH];
+  // NS == 0: fp32 tiles; NS > 0: K as row-major bf16 planes, V as transposed bf16 planes (stage_split)
+  constexpr int LDS_A = NS > 0 ? rowm_elems(HD, NSS) * 2 : 32 * PITCH * 4, LDS_B = NS > 0 ? trans_elems(HD, NSS) * 2 : 32 * PITCH * 4;
+  __shared__ __attribute__((aligned(16))) char lds_a[LDS_A];
+  __shared__ __attribute__((aligned(16))) char lds_b[LDS_B];
+  float* sK = reinterpret_cast<float*>(lds_a);
+  float* sV = reinterpret_cast<float*>(lds_b);
+  unsigned short* pK = reinterpret_cast<unsigned short*>(lds_a);
+  unsigned short* pVt = reinterpret_cast<unsigned short*>(lds_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int head = blockIdx.y;
   const Seq sq = seq_of(p, blockIdx.z);
@@ -162,12 +234,28 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = p.scale * LOG2E;
   const int nt = (sq.lk + 31) / 32;
+  f32x4_t gk[NS > 0 ? HD / 32 : 1], gv[NS > 0 ? HD / 32 : 1];      // split path: the next tile's rows, in flight during the current tile
+  if constexpr (NS > 0) {
+    tile_load<HD>(p.k + sq.ko, p.k_ls, head, 0, sq.lk, gk, tid);
+    tile_load<HD>(p.v + sq.vo, p.v_ls, head, 0, sq.lk, gv, tid);
+  }
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * 32;
     __syncthreads();
-    stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
-    stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    if constexpr (NS > 0) {
+      tile_store<HD, NSS, true, false>(gk, pK, nullptr, tid);
+      tile_store<HD, NSS, false, true>(gv, nullptr, pVt, tid);
+    } else {
+      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
+      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    }
     __syncthreads();
+    if constexpr (NS > 0) {
+      if (t + 1 < nt) {
+        tile_load<HD>(p.k + sq.ko, p.k_ls, head, kv0 + 32, sq.lk, gk, tid);
+        tile_load<HD>(p.v + sq.vo, p.v_ls, head, kv0 + 32, sq.lk, gv, tid);
+      }
+    }
     f32x16_t sa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[r] = 0.f;
@@ -175,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
 #pragma unroll
       for (int s = 0; s < KB; ++s) {
         bf16x8_t ka[NSS];
-        lds_frag<NSS>(sK + (lane & 31) * PITCH + 16 * s + 8 * h, 1, ka);
+        rowm_frag<HD, NSS>(pK, lane & 31, 16 * s + 8 * h, ka);
         sa = mma_split<NSS>(ka, qs[s], sa);
       }
     } else {
@@ -213,11 +301,8 @@ __global__ __launch_bounds__(256, 1) void attn_f32_fwd_k(const AP p) {
         acc_frag<NSS>(sa, j, pb);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          float x[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) x[i] = sV[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
           bf16x8_t va[NSS];
-          split8<NSS>(x, va);
+          trans_frag<HD, NSS>(pVt, 32 * b + (lane & 31), j, h, va);
           o[b] = mma_split<NSS>(va, pb, o[b]);
         }
       }
@@ -261,14 +346,22 @@ __global__ __launch_bounds__(256) void attn_f32_delta_k(const AP p) {
 
 // ----------------------------------------------------------------------------- backward dQ
 template <int HD, int NS = 0>
-__global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p) {
   constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;
   constexpr int PITCH = HDP + 1;
-  __shared__ float sK[32 * PITCH];
-  __shared__ float sV[32 * PITCH];
+  // NS > 0: K as row-major AND transposed bf16 planes, V as row-major planes
+  constexpr int LDS_A = NS > 0 ? (rowm_elems(HD, NSS) + trans_elems(HD, NSS)) * 2 : 32 * PITCH * 4;
+  constexpr int LDS_B = NS > 0 ? rowm_elems(HD, NSS) * 2 : 32 * PITCH * 4;
+  __shared__ __attribute__((aligned(16))) char lds_a[LDS_A];
+  __shared__ __attribute__((aligned(16))) char lds_b[LDS_B];
+  float* sK = reinterpret_cast<float*>(lds_a);
+  float* sV = reinterpret_cast<float*>(lds_b);
+  unsigned short* pK = reinterpret_cast<unsigned short*>(lds_a);
+  unsigned short* pKt = pK + (NS > 0 ? rowm_elems(HD, NSS) : 0);
+  unsigned short* pV = reinterpret_cast<unsigned short*>(lds_b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int head = blockIdx.y;
   const Seq sq = seq_of(p, blockIdx.z);
@@ -296,12 +389,28 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
   const int nt = (sq.lk + 31) / 32;
+  f32x4_t gk[NS > 0 ? HD / 32 : 1], gv[NS > 0 ? HD / 32 : 1];
+  if constexpr (NS > 0) {
+    tile_load<HD>(p.k + sq.ko, p.k_ls, head, 0, sq.lk, gk, tid);
+    tile_load<HD>(p.v + sq.vo, p.v_ls, head, 0, sq.lk, gv, tid);
+  }
   for (int t = 0; t < nt; ++t) {
     const int kv0 = t * 32;
     __syncthreads();
-    stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
-    stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    if constexpr (NS > 0) {
+      tile_store<HD, NSS, true, true>(gk, pK, pKt, tid);
+      tile_store<HD, NSS, true, false>(gv, pV, nullptr, tid);
+    } else {
+      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
+      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+    }
     __syncthreads();
+    if constexpr (NS > 0) {
+      if (t + 1 < nt) {
+        tile_load<HD>(p.k + sq.ko, p.k_ls, head, kv0 + 32, sq.lk, gk, tid);
+        tile_load<HD>(p.v + sq.vo, p.v_ls, head, kv0 + 32, sq.lk, gv, tid);
+      }
+    }
     f32x16_t sa, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -309,8 +418,8 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
 #pragma unroll
       for (int s = 0; s < KB; ++s) {
         bf16x8_t ka[NSS], va[NSS];
-        lds_frag<NSS>(sK + (lane & 31) * PITCH + 16 * s + 8 * h, 1, ka);
-        lds_frag<NSS>(sV + (lane & 31) * PITCH + 16 * s + 8 * h, 1, va);
+        rowm_frag<HD, NSS>(pK, lane & 31, 16 * s + 8 * h, ka);
+        rowm_frag<HD, NSS>(pV, lane & 31, 16 * s + 8 * h, va);
         sa = mma_split<NSS>(ka, qs[s], sa);
         dp = mma_split<NSS>(va, dos[s], dp);
       }
@@ -334,11 +443,8 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
         acc_frag<NSS>(sa, j, sb);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          float x[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) x[i] = sK[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
           bf16x8_t ka[NSS];
-          split8<NSS>(x, ka);
+          trans_frag<HD, NSS>(pKt, 32 * b + (lane & 31), j, h, ka);
           dq[b] = mma_split<NSS>(ka, sb, dq[b]);
         }
       }
@@ -363,14 +469,22 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dq_k(const AP p) {
 
 // ----------------------------------------------------------------------------- backward dK, dV
 template <int HD, int NS = 0>
-__global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP p) {
   constexpr int NSS = NS > 0 ? NS : 1, KB = NS > 0 ? HD / 16 : 1;
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int NB = HDP / 32;
   constexpr int KS = HD / 2;
   constexpr int PITCH = HDP + 1;
-  __shared__ float sQ[32 * PITCH];
-  __shared__ float sDO[32 * PITCH];
+  // NS > 0: Q and dO as row-major AND transposed bf16 planes
+  constexpr int LDS_A = NS > 0 ? (rowm_elems(HD, NSS) + trans_elems(HD, NSS)) * 2 : 32 * PITCH * 4;
+  __shared__ __attribute__((aligned(16))) char lds_a[LDS_A];
+  __shared__ __attribute__((aligned(16))) char lds_b[LDS_A];
+  float* sQ = reinterpret_cast<float*>(lds_a);
+  float* sDO = reinterpret_cast<float*>(lds_b);
+  unsigned short* pQ = reinterpret_cast<unsigned short*>(lds_a);
+  unsigned short* pQt = pQ + (NS > 0 ? rowm_elems(HD, NSS) : 0);
+  unsigned short* pDO = reinterpret_cast<unsigned short*>(lds_b);
+  unsigned short* pDOt = pDO + (NS > 0 ? rowm_elems(HD, NSS) : 0);
   __shared__ float sLse[32];
   __shared__ float sDlt[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -398,17 +512,33 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
   const int nt = (sq.lq + 31) / 32;
+  f32x4_t gq[NS > 0 ? HD / 32 : 1], gd[NS > 0 ? HD / 32 : 1];
+  if constexpr (NS > 0) {
+    tile_load<HD>(p.q + sq.qo, p.q_ls, head, 0, sq.lq, gq, tid);
+    tile_load<HD>(p.dout + sq.doo, p.do_ls, head, 0, sq.lq, gd, tid);
+  }
   for (int t = 0; t < nt; ++t) {
     const int qq0 = t * 32;
     __syncthreads();
-    stage<HD, HDP, 32, PITCH>(p.q + sq.qo, p.q_ls, head, qq0, sq.lq, sQ, tid);
-    stage<HD, HDP, 32, PITCH>(p.dout + sq.doo, p.do_ls, head, qq0, sq.lq, sDO, tid);
+    if constexpr (NS > 0) {
+      tile_store<HD, NSS, true, true>(gq, pQ, pQt, tid);
+      tile_store<HD, NSS, true, true>(gd, pDO, pDOt, tid);
+    } else {
+      stage<HD, HDP, 32, PITCH>(p.q + sq.qo, p.q_ls, head, qq0, sq.lq, sQ, tid);
+      stage<HD, HDP, 32, PITCH>(p.dout + sq.doo, p.do_ls, head, qq0, sq.lq, sDO, tid);
+    }
     if (tid < 32) {
       const int qp = qq0 + tid;
       sLse[tid] = qp < sq.lq ? p.lse[stat_idx(p, head, sq.stat0, qp)] * LOG2E : 0.f;
       sDlt[tid] = qp < sq.lq ? p.delta[stat_idx(p, head, sq.stat0, qp)] : 0.f;
     }
     __syncthreads();
+    if constexpr (NS > 0) {
+      if (t + 1 < nt) {
+        tile_load<HD>(p.q + sq.qo, p.q_ls, head, qq0 + 32, sq.lq, gq, tid);
+        tile_load<HD>(p.dout + sq.doo, p.do_ls, head, qq0 + 32, sq.lq, gd, tid);
+      }
+    }
     f32x16_t sa, dp, pa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
@@ -416,8 +546,8 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
 #pragma unroll
       for (int s = 0; s < KB; ++s) {
         bf16x8_t qa[NSS], da[NSS];
-        lds_frag<NSS>(sQ + (lane & 31) * PITCH + 16 * s + 8 * h, 1, qa);
-        lds_frag<NSS>(sDO + (lane & 31) * PITCH + 16 * s + 8 * h, 1, da);
+        rowm_frag<HD, NSS>(pQ, lane & 31, 16 * s + 8 * h, qa);
+        rowm_frag<HD, NSS>(pDO, lane & 31, 16 * s + 8 * h, da);
         sa = mma_split<NSS>(qa, ks[s], sa);
         dp = mma_split<NSS>(da, vs[s], dp);
       }
@@ -444,15 +574,9 @@ __global__ __launch_bounds__(256, 1) void attn_f32_dkv_k(const AP p) {
         acc_frag<NSS>(sa, j, sb);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          float x[8], y[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            x[i] = sDO[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
-            y[i] = sQ[acc_row(8 * j + i, h) * PITCH + 32 * b + (lane & 31)];
-          }
           bf16x8_t da[NSS], qa[NSS];
-          split8<NSS>(x, da);
-          split8<NSS>(y, qa);
+          trans_frag<HD, NSS>(pDOt, 32 * b + (lane & 31), j, h, da);
+          trans_frag<HD, NSS>(pQt, 32 * b + (lane & 31), j, h, qa);
           dv[b] = mma_split<NSS>(da, pb, dv[b]);
           dk[b] = mma_split<NSS>(qa, sb, dk[b]);
         }
