@@ -571,30 +571,50 @@ def rope_(qkv, row_pos, cos, sin, n_heads: int, head_dim: int, nrows=None):
 
 # ----------------------------------------------------------------------------- var-len attention (bf16)
 class _Attention(Function):
+    """`rope` = (row_pos, cos, sin, nrows): q and k are rotated IN PLACE on the packed qkv buffer before the attention (the standalone
+    `_Rope` node's job) and the inverse rotation is applied in place to this node's own dqkv in the backward — no copy of the incoming
+    gradient (the standalone node must clone it: 100 MB per decoder layer) and one autograd node less per layer."""
+
     @staticmethod
-    def forward(ctx, qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max):
+    def forward(ctx, qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, rope=None):
         hdim = n_heads * head_dim
+        if rope is not None:
+            row_pos, cos, sin, nrows = rope
+            ctx.mark_dirty(qkv)
+            K.rope_(qkv, row_pos, cos, sin, n_heads, head_dim, False, nrows)
         q, k, v = qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:]
         out, lse = K.attn_fwd(q, k, v, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max)
-        ctx.save_for_backward(qkv, out, lse, cu_seqlens, row_of_pos)
-        ctx.cfg = (max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
+        ctx.save_for_backward(qkv, out, lse, cu_seqlens, row_of_pos, *(rope if rope is not None else ()))
+        ctx.cfg = (max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, rope is not None)
+        if rope is not None:
+            ctx.set_materialize_grads(False)
+            return out, qkv                 # (the rotated buffer is an output because it was modified in place)
         return out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dout):
-        qkv, out, lse, cu_seqlens, row_of_pos = ctx.saved_tensors
-        max_seqlen, n_heads, head_dim, scale, causal, total_pos_max = ctx.cfg
+    def backward(ctx, dout, dqkv_direct=None):
+        max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, roped = ctx.cfg
+        saved = ctx.saved_tensors               # (once: checkpointing unpacks on access)
+        qkv, out, lse, cu_seqlens, row_of_pos = saved[:5]
         hdim = n_heads * head_dim
         q, k, v = qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:]
         dqkv = K.attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos,
-                          total_pos_max)
-        return dqkv.view(qkv.shape), None, None, None, None, None, None, None, None
+                          total_pos_max).view(qkv.shape)
+        if roped:
+            if dqkv_direct is not None:      # somebody differentiated through the rotated buffer itself (the training step never does)
+                dqkv = dqkv + dqkv_direct
+            row_pos, cos, sin, nrows = saved[5:]
+            K.rope_(dqkv, row_pos, cos, sin, n_heads, head_dim, True, nrows)
+        return dqkv, None, None, None, None, None, None, None, None, None
 
 
 def attention(qkv, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, causal: bool,
-              row_of_pos=None, total_pos_max: int | None = None):
-    """qkv: [rows, 3*H*hd] packed (q | k | v) -> [rows, H*hd]"""
+              row_of_pos=None, total_pos_max: int | None = None, rope=None):
+    """qkv: [rows, 3*H*hd] packed (q | k | v) -> [rows, H*hd]. `rope` = (row_pos, cos, sin, nrows): rotate q / k in place first (and
+    un-rotate the gradient in the backward) — `rope_` + `attention` in one autograd node"""
+    if rope is not None:
+        return _Attention.apply(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, tuple(rope))[0]
     return _Attention.apply(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
 
 

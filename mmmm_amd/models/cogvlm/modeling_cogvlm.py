@@ -142,7 +142,9 @@ class VisionExpertAttention(nn.Module):
         else:
             qkv = gated_linear(x, self.vision_expert_query_key_value, self.language_expert_query_key_value, rt.counts)
         cos, sin = self.rotary_emb.tables(rt.n_pos, x.device)
-        qkv = Fh.rope_(qkv, rt.row_pos, cos, sin, self.num_heads, self.head_dim, rt.n_rows)
+        fuse_rope = rt.kv is None and rt.kv_lens is None      # training / plain forward: rotation inside the attention node
+        if not fuse_rope:
+            qkv = Fh.rope_(qkv, rt.row_pos, cos, sin, self.num_heads, self.head_dim, rt.n_rows)
         if rt.kv is not None:               # generation: the rotated K / V rows of this call join the cache (:253-262)
             rt.kv.append(self.layer_idx, qkv, self.hidden_size, rt.n_rows)
         if rt.kv_lens is not None:          # decode step: one query per sample against the cache (:129-141)
@@ -150,7 +152,8 @@ class VisionExpertAttention(nn.Module):
                                 self.num_heads, self.head_dim, self.head_dim ** -0.5, rt.kv.attn_bound())
         else:
             ctx = Fh.attention(qkv, rt.cu_seqlens, rt.L, self.num_heads, self.head_dim, self.head_dim ** -0.5, True,
-                               row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L)
+                               row_of_pos=rt.row_of_pos, total_pos_max=rt.B * rt.L,
+                               rope=(rt.row_pos, cos, sin, rt.n_rows) if fuse_rope else None)
         if decode:
             return linear_decode(ctx, self.language_expert_dense, residual)
         return gated_linear(ctx, self.vision_expert_dense, self.language_expert_dense, rt.counts, residual=residual)
