@@ -258,6 +258,21 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+_JSON_OUT = None
+
+
+def reserve_stdout():
+    """stdout carries ONE JSON line and nothing else. Libraries that print from C write to fd 1 as well (RCCL's version banner at the first
+    collective: five lines on rank 0's stdout) — so from here on fd 1 is an alias of stderr and the JSON line goes to a private duplicate
+    of the original stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
 def dry_run_cpu(args, rank: int, world: int):
     """the N-rank plumbing of this file (rendezvous, bucketed all-reduce overlapped with backward, barrier + max-over-ranks
     timing, one JSON line from rank 0) on CPU tensors over gloo. The VividMed model itself has no CPU path: a toy network
@@ -307,7 +322,7 @@ def dry_run_cpu(args, rank: int, world: int):
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
                           'data': 'dry-run (CPU, toy network): launcher / collective plumbing check, NOT a measurement',
                           'dry_run': True, 'config': {'workload': 'dry-run-cpu', 'parallelism': f'dp{world}', 'backend': 'gloo'},
-                          'loss': float(loss.detach())}), flush=True)
+                          'loss': float(loss.detach())}), file=reserve_stdout(), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -346,6 +361,7 @@ def main():
     # initialised HIP must never exec / be replaced, children are the only safe way.
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    reserve_stdout()          # (after the self-launch branch: the child ranks inherit the real stdout) before anything that may print from C
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -543,7 +559,7 @@ def main():
                 out['gemm_f32'] = {'achieved_tflops': fl_f / (ms_f * 1e-3) / 1e12, 'launches': n_f, 'kernel_time_share': ms_f * 1e-3 / dt}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, model.config)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=reserve_stdout(), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
