@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           gemm_ext_scale4<true>(p, row0 + wm * 64 + j * 16 + frow, n0 + wn * (NI * 16) + i * 16 + fq * 4, acc[i][j]);
-    } else {
+    } else if (p.alpha2 != 1.f) {      // (rsLoRA with r = 64, alpha = 8: the scale is exactly 1 — nothing to do)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll

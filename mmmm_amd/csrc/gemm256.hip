@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           gemm_ext_scale4<true>(p, row0 + wm * 32 * MI + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
-    } else {
+    } else if (p.alpha2 != 1.f) {      // (rsLoRA with r = 64, alpha = 8: the scale is exactly 1 — nothing to do)
 #pragma unroll
       for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
