@@ -420,6 +420,7 @@ def main():
 
     from mmmm_amd.models.lora import ActivationBudget
     plan = 'every layer recomputed'
+    import mmmm_amd.functional as Fh
     side_stream_note = ['on' if Fh.WGRAD_SIDE_STREAM else 'off (VM_WGRAD_STREAM=0)']
     if args.checkpointing == 'hbm':
         # planning step (untimed, not a warmup step): peak HBM with every layer checkpointed -> what is left over
