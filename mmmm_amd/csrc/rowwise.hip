@@ -437,6 +437,46 @@ __global__ __launch_bounds__(256) void transpose_k(const T* __restrict__ in, int
   }
 }
 
+// fp32 fast path (the heads' weight gradients transpose dy and x of every unfrozen linear: 639 launches per step): 16-byte loads along the
+// input rows, 16-byte stores along the output rows, the transposition in LDS. Needs ld_in, ld_out % 4 == 0, 16-byte aligned bases and
+// an output pitch that holds whole 64-row tiles (callers pad rows to 64); same zero fill and optional column sums as transpose_k.
+__global__ __launch_bounds__(256) void transpose_f32_vec_k(const float* __restrict__ in, int64_t ld_in, float* __restrict__ out, int64_t ld_out,
+                                                           int rows, int cols, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];          // tile[c][r]
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x, q = t & 15, p = t >> 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = r0 + p + 16 * it, c = c0 + 4 * q;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* src = in + (int64_t)r * ld_in + c;
+      if (c + 3 < cols) v = *reinterpret_cast<const f32x4_t*>(src);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = src[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[4 * q + e][p + 16 * it] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int oc = p + 16 * it;             // output row = input column
+    if (c0 + oc < cols) {
+      const f32x4_t v = {tile[oc][4 * q], tile[oc][4 * q + 1], tile[oc][4 * q + 2], tile[oc][4 * q + 3]};
+      *reinterpret_cast<f32x4_t*>(out + (int64_t)(c0 + oc) * ld_out + r0 + 4 * q) = v;
+    }
+  }
+  if (colsum && t < 64 && c0 + t < cols) {
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) a += tile[t][r];
+    atomicAdd(colsum + c0 + t, a);
+  }
+}
+
 // one launch for a whole table of small transposes (every LoRA factor of the model after an optimizer step):
 // desc[i] = {src, dst, rows, cols, ld_src, ld_dst} as int64; blockIdx.y = table entry, blockIdx.x = 64x64 tile
 template <typename T>
@@ -869,10 +909,20 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
   return VM_OK;
 }
 
+static bool transpose_vec_ok(const void* in, int64_t ld_in, const void* out, int64_t ld_out, int rows) {
+  return ld_in % 4 == 0 && ld_out % 4 == 0 && aligned16(in) && aligned16(out) && ld_out >= (int64_t)((rows + 63) / 64) * 64;
+}
+
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
                  const int32_t* nrows_dev, void* stream) {
   if (rows <= 0 || cols <= 0) return VM_OK;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == VM_F32 && !nrows_dev && transpose_vec_ok(in, ld_in, out, ld_out, rows)) {
+    hipLaunchKernelGGL(transpose_f32_vec_k, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld_in, (float*)out, ld_out, rows, cols,
+                       (float*)nullptr);
+    VM_LAUNCH_CHECK();
+    return VM_OK;
+  }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                            ld_in, (T*)out, ld_out, rows, cols, nrows_dev, (const int32_t*)nullptr, 0));
   VM_LAUNCH_CHECK();
@@ -884,6 +934,12 @@ int vm_transpose_colsum(const void* in, int64_t ld_in, void* out, int64_t ld_out
   if (rows <= 0 || cols <= 0) return VM_OK;
   if (!colsum_accum) return VM_ERR_BAD_ARG;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (dtype == VM_F32 && transpose_vec_ok(in, ld_in, out, ld_out, rows)) {
+    hipLaunchKernelGGL(transpose_f32_vec_k, grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, ld_in, (float*)out, ld_out, rows, cols,
+                       colsum_accum);
+    VM_LAUNCH_CHECK();
+    return VM_OK;
+  }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(transpose_k<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in,
                                            ld_in, (T*)out, ld_out, rows, cols, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, colsum_accum));
   VM_LAUNCH_CHECK();

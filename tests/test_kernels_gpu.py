@@ -177,6 +177,21 @@ def test_gemm_f32_accumulate_into_existing_output(dev, K, M, N, Kd, split):
     assert rel_err(out, ref) < (2e-6 if split == 0 else 1.5e-5)
 
 
+@pytest.mark.parametrize('rows,cols', [(3136, 768), (3136, 3072), (100, 70), (64, 64), (65, 132), (12544, 384)])
+def test_transpose_f32_vector_path(dev, K, rows, cols):
+    """the 16-byte fp32 path (heads' weight gradients): exact transposition, zero K padding, column sums riding along"""
+    x = torch.randn(rows, cols, device=dev)
+    y = K.transpose(x, pad_to=64)
+    rp = (rows + 63) // 64 * 64
+    assert y.shape == (cols, rp) and torch.equal(y[:, :rows], x.T) and bool(torch.all(y[:, rows:] == 0))
+    acc = torch.ones(cols, device=dev)
+    y2 = K.transpose(x, pad_to=64, colsum_out=acc)
+    assert torch.equal(y2, y)
+    assert rel_err(acc, 1 + x.double().sum(0)) < 1e-5
+    xs = torch.randn(rows, cols + 4, device=dev)[:, :cols]          # a row pitch that is not the width
+    assert torch.equal(K.transpose(xs, pad_to=64)[:, :rows], xs.T)
+
+
 def test_transpose(dev, K):
     for dt in (torch.bfloat16, torch.float32):
         x = torch.randn(130, 200, device=dev).to(dt)
