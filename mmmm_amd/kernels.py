@@ -784,8 +784,10 @@ def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: fl
         dq, dk, dv = grads
         assert all(g.stride() == t.stride() for g, t in zip(grads, (q, k, v)))
     else:
-        dq, dk, dv = torch.zeros_like(q, memory_format=torch.contiguous_format), torch.zeros_like(k, memory_format=torch.contiguous_format), \
-            torch.zeros_like(v, memory_format=torch.contiguous_format)
+        # (every row of a dense [Bn, L, C] operand is written by the dQ / dKV kernels: no zero fill; packed rows past cu[-1] would not be)
+        mk = torch.empty_like if cu_seqlens is None else torch.zeros_like
+        dq, dk, dv = mk(q, memory_format=torch.contiguous_format), mk(k, memory_format=torch.contiguous_format), \
+            mk(v, memory_format=torch.contiguous_format)
         q, k, v = _c(q), _c(k), _c(v)
     a = _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens)
     if cu_seqlens is not None and max_seqlen is not None:
