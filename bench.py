@@ -258,6 +258,42 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def gemm_source_digest() -> str:
+    """sha256 (first 16 hex digits) over the sources of the dominant GEMM kernel: ties a committed PMC measurement to the code it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('gemm256.hip', 'gemm.hip', 'gemm_common.hpp', 'vm_tile.hpp'):
+        h.update((ROOT / 'mmmm_amd' / 'csrc' / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def run_also(workloads: list, args) -> list:
+    """other workloads of BASELINE.json (phase-vlm: the one the north_star's 50 % target is quoted on) measured by child processes of
+    this script, one after the other, BEFORE this process touches the GPU (a child needs the HBM to itself). Returns their
+    condensed lines."""
+    import subprocess
+    out = []
+    for wl in workloads:
+        if wl not in WORKLOADS:
+            raise SystemExit(f'--also: unknown workload {wl}')
+        cmd = [sys.executable, str(Path(__file__).resolve()), '--workload', wl, '--steps', '12', '--warmup', '3', '--no-cpu-baseline',
+               '--no-kernel-events', '--also', '', '--batch', str(args.batch), '--checkpointing', args.checkpointing,
+               '--hbm-fraction', str(args.hbm_fraction)]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith('{')), None)
+        if r.returncode != 0 or line is None:
+            out.append({'workload': wl, 'error': f'exit code {r.returncode}'})
+            continue
+        j = json.loads(line)
+        out.append({'workload': wl, 'description': j['config']['description'], 'value': j['value'], 'unit': j['unit'],
+                    'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'],
+                    'mfma_utilisation_step': j['mfma_utilisation_step'], 'model_tflops_per_image': j['model_tflops_per_image'],
+                    'gradient_checkpointing': j['config']['gradient_checkpointing'], 'wgrad_side_stream': j['config']['wgrad_side_stream'],
+                    'wall_s': round(time.perf_counter() - t0, 1)})
+    return out
+
+
 _JSON_OUT = None
 
 
@@ -354,6 +390,9 @@ def main():
                     help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
     ap.add_argument('--event-stride', type=int, default=4, help='bracket a pseudo-random 1-in-n sample of the launches of the dominant kernel with HIP events')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
+    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed'),
+                    help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
+                         "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
     args = ap.parse_args()
 
     # N > 1 from a plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run and pass its
@@ -361,6 +400,9 @@ def main():
     # initialised HIP must never exec / be replaced, children are the only safe way.
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    also = []
+    if args.also and args.gpus == 1 and 'WORLD_SIZE' not in os.environ and not args.dry_run_cpu and args.depth_scale == 1.0 and not args.fp8:
+        also = run_also([w for w in args.also.split(',') if w and w != args.workload], args)
     reserve_stdout()          # (after the self-launch branch: the child ranks inherit the real stdout) before anything that may print from C
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -383,6 +425,7 @@ def main():
     from mmmm_amd.ddp import BucketedGradAllReduce
     w = WORKLOADS[args.workload]
     model, tok = build(w, device, args.depth_scale)
+    model.trainer.is_parallel = world > 1          # Lightning's flag (mmmm.py:263: dummy head forwards on ranks that used none)
     n_fp8 = 0
     if args.fp8:
         from mmmm_amd.models.lora import enable_fp8
@@ -454,8 +497,7 @@ def main():
             except torch.OutOfMemoryError:        # the plan did not even fit: shrink hard and try again
                 if use_dist:
                     raise                          # (ranks must take the same number of collectives: no local retries)
-                ddp.zero_grad()
-                torch.cuda.synchronize()
+                ddp.abort_step()                  # buckets, fp32 side accumulators, tensors parked by the aborted backward pass
                 torch.cuda.empty_cache()
                 ActivationBudget.limit = int(ActivationBudget.limit * 0.6)
                 if rank == 0:
@@ -501,9 +543,12 @@ def main():
     torch.cuda.synchronize()
     model.freeze_python_gc()          # model, buckets, optimizer state and the batch are permanent: keep the cyclic GC off them
     ms0 = torch.cuda.memory_stats(device)
+    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0          # until every launch of the step is enqueued (the host never waits inside a step)
     torch.cuda.synchronize()
     ms1 = torch.cuda.memory_stats(device)
     if use_dist:
@@ -516,6 +561,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_v = float(loss.item())
+    if world > 1:
+        ddp.assert_replicas_equal(what='trainable parameters after the timed region')       # identical updates of averaged gradients
 
     if rank == 0:
         images = world * args.batch * args.steps
@@ -529,6 +576,7 @@ def main():
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
                        'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
+            'host_enqueue_ms': host_s / args.steps * 1e3,
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
             # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
             'allocator': {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
@@ -542,10 +590,16 @@ def main():
             alg_bytes = K.prof_last_bytes() / max(n, 1)
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic, traffic_src = None, None
-            tf = Path(__file__).resolve().parent / 'profiles' / 'r2_gemm_traffic.json'
-            if tf.exists():          # PMC passes cannot run inside this process: the committed rocprofv3 measurement
+            cands = sorted((Path(__file__).resolve().parent / 'profiles').glob('r*_gemm_traffic.json'))
+            if cands:          # PMC passes cannot run inside this process: the newest committed rocprofv3 measurement ...
+                tf = cands[-1]
                 tj = json.loads(tf.read_text())
-                traffic, traffic_src = tj['bytes_per_launch'], 'profiles/r2_gemm_traffic.json: ' + tj['source']
+                digest = gemm_source_digest()
+                if tj.get('source_digest') == digest:      # ... if it was taken on THESE kernel sources
+                    traffic, traffic_src = tj['bytes_per_launch'], f'profiles/{tf.name}: ' + tj['source']
+                else:
+                    traffic_src = (f'profiles/{tf.name} is STALE (kernel sources changed since it was measured: digest {tj.get("source_digest")} '
+                                   f'vs {digest}; it held {tj["bytes_per_launch"]:.3e} bytes per launch) — re-run tools/pmc_traffic.sh')
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
                                'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
@@ -558,6 +612,8 @@ def main():
             ms_f, fl_f, n_f = K.prof_collect(hip.PROF_GEMM_F32)
             if n_f:
                 out['gemm_f32'] = {'achieved_tflops': fl_f / (ms_f * 1e-3) / 1e12, 'launches': n_f, 'kernel_time_share': ms_f * 1e-3 / dt}
+        if also:
+            out['also'] = also
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, model.config)
         print(json.dumps(out), file=reserve_stdout(), flush=True)

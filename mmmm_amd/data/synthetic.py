@@ -120,5 +120,5 @@ def make_batch(image_shapes: list[tuple], patch_sizes: list[tuple], pool_sizes: 
         masks=[mv(x) for x in masks], boxes=[mv(x) for x in boxes], index_offsets=[mv(x) for x in offsets],
         instance_mask=list(instance), vg_label_mask=[None] * B,
         # the collate output before the move to the device: the step reads token ids / box offsets on the host (models/mmmm.py)
-        host=dict(input_ids=vi['input_ids'], index_offsets=list(offsets)),
+        host=dict(input_ids=vi['input_ids'], labels=vi['labels'], index_offsets=list(offsets)),
     )

@@ -44,7 +44,7 @@ class BucketedGradAllReduce:
     `p._vm_grad_ready(p)` only REGISTERS the stream the kernel ran on; it never counts."""
 
     def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, sync_params: bool = True):
         self.params = [p for p in params if p.requires_grad]
         self.pg = process_group
         if world_size is None:
@@ -63,6 +63,9 @@ class BucketedGradAllReduce:
         self._f32_tables: dict[int, torch.Tensor] = {}                # bucket index -> device table (rebuilt when entries are added)
         self._hooks = []
         self._acc_nodes = []                      # the hooks live on the AccumulateGrad nodes: keep the nodes alive
+        assert torch.is_grad_enabled(), 'BucketedGradAllReduce must be built with autograd enabled (it hooks the AccumulateGrad nodes)'
+        if self.world_size > 1 and sync_params:
+            self.sync_parameters()
         for p in self.params:
             acc = p.view_as(p).grad_fn.next_functions[0][0]
             self._acc_nodes.append(acc)
@@ -102,6 +105,50 @@ class BucketedGradAllReduce:
                 off += (p.numel() + 7) // 8 * 8
             b.pending = len(lst)
             self.buckets.append(b)
+
+    # -- replica consistency -------------------------------------------------------------------
+    @torch.no_grad()
+    def sync_parameters(self, extra: tuple = ()):
+        """What DDPStrategy does when it wraps the module (conf/phase-vg/fit.yaml:11-15; torch DDP's `_sync_module_states`): rank 0's
+        trainable parameters (and `extra` tensors: optimizer state on resume) are broadcast to every rank, packed per dtype into a few
+        large messages (xGMI is per-link bound: few big transfers), then every rank checks that it holds rank 0's bytes — an
+        order-independent integer checksum, all-reduced with MIN and MAX, must agree."""
+        if not (dist.is_available() and dist.is_initialized()) or self.world_size <= 1:
+            return
+        tensors = [p.data for p in self.params] + [t for t in extra if t is not None]
+        groups: dict = {}
+        for t in tensors:
+            groups.setdefault((t.dtype, t.device), []).append(t)
+        for (dtype, device), ts in groups.items():
+            for i in range(0, len(ts), 512):
+                chunk = ts[i:i + 512]
+                flat = torch.cat([t.reshape(-1) for t in chunk])
+                dist.broadcast(flat, 0, group=self.pg)
+                off = 0
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+        self.assert_replicas_equal(tensors)
+
+    @torch.no_grad()
+    def assert_replicas_equal(self, tensors=None, what: str = 'trainable parameters'):
+        """raise unless every rank holds bit-identical `tensors` (default: the trainable parameters)"""
+        if not (dist.is_available() and dist.is_initialized()) or self.world_size <= 1:
+            return
+        tensors = [p.data for p in self.params] if tensors is None else list(tensors)
+        dev = tensors[0].device
+        acc = torch.zeros(2, dtype=torch.int64, device=dev)
+        for t in tensors:
+            b = t.detach().contiguous().view(torch.uint8) if t.element_size() == 1 else t.detach().contiguous().view(
+                {2: torch.int16, 4: torch.int32, 8: torch.int64}[t.element_size()])
+            v = b.reshape(-1).to(torch.int64)
+            acc[0] += v.sum()
+            acc[1] += (v * (torch.arange(v.numel(), device=dev, dtype=torch.int64) % 65521 + 1)).sum()      # position-sensitive
+        lo, hi = acc.clone(), acc.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f'data-parallel replicas diverged: {what} differ between ranks (checksum min {lo.tolist()} max {hi.tolist()})')
 
     @property
     def total_bytes(self) -> int:
@@ -150,6 +197,11 @@ class BucketedGradAllReduce:
     def _mark_ready(self, p: torch.Tensor):
         """autograd has finished p's AccumulateGrad node: every use of p has reported, the slot is final"""
         if id(p) in self._ready:
+            if self.collectives and self.buckets[self._bucket_of[id(p)]].launched:
+                # a second backward pass before finish(): this slot's bucket has already been all-reduced, the new contribution
+                # would be added to the SUM of all ranks and never exchanged — silently wrong gradients
+                raise RuntimeError('BucketedGradAllReduce: a parameter received a gradient after its bucket was reduced — with '
+                                   'collectives on, run exactly one backward pass per finish() (no local gradient accumulation)')
             return
         self._ready.add(id(p))
         b = self.buckets[self._bucket_of[id(p)]]
@@ -215,6 +267,24 @@ class BucketedGradAllReduce:
             inv = 1.0 / self.world_size
             for b in self.buckets:
                 b.buffer.mul_(inv)
+
+    def abort_step(self):
+        """Bring the exchange back to a clean state after a forward / backward pass that RAISED (bench.py's calibration retries after
+        an out-of-memory error): wait for the device, drop the references the backward pass parked (functional._HELD — the engine
+        discards its final callbacks when a pass raises), forget the side stream's lag ring, zero the buckets AND the fp32 side
+        accumulators (partial norm-gradient sums of the aborted pass: `zero_grad` alone leaves them to be folded into the next
+        step's gradients), reset the readiness counters."""
+        from . import functional as Fh
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+        if self.buckets and self.buckets[0].buffer.is_cuda:
+            torch.cuda.synchronize(self.buckets[0].buffer.device)
+        Fh.abort_backward_state()
+        for buf, _ in self._f32_chunks:
+            buf.zero_()
+        self.zero_grad()
 
     def zero_grad(self):
         off_fix = False

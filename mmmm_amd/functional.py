@@ -115,6 +115,9 @@ SIDE_LAG = int(os.environ.get('VM_SIDE_LAG', '24'))          # forked calls the 
 _HELD: list = []              # tensors kept referenced until the running backward pass ends (_hold_until_backward_ends)
 
 
+_HELD_TASK = [None]          # graph-task id of the backward pass `_HELD` belongs to
+
+
 def _hold_until_backward_ends(t: torch.Tensor):
     """Keep a second reference to `t` until autograd finishes the current backward pass.
     The output gradient `dy` of a linear with a fused residual is handed back to autograd as the residual's gradient, and the
@@ -123,10 +126,30 @@ def _hold_until_backward_ends(t: torch.Tensor):
     reading it. `record_stream` does not help (it only stops the allocator from recycling FREED memory). A second reference
     makes the engine add out of place; once the backward pass is over nothing accumulates any more and the reference goes.
     (Found by replaying a full-size step, tests/test_fullsize_gpu.py: the LoRA-B gradients of the decoder's dense / down_proj
-    linears came out different on every run.)"""
-    if not _HELD:
-        torch.autograd.Variable._execution_engine.queue_callback(_HELD.clear)
+    linears came out different on every run.)
+    The release callback is registered once per BACKWARD PASS, keyed on the engine's graph-task id: the engine drops its final
+    callbacks when a backward pass raises (an out-of-memory error in the calibration steps of bench.py), and a registration keyed on
+    "the list is empty" would then never happen again — every later step would append its dy tensors and free none."""
+    task = torch._C._current_graph_task_id()
+    if task != _HELD_TASK[0]:
+        _HELD.clear()                     # (left over from a pass that raised)
+        _HELD_TASK[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_release_held)
     _HELD.append(t)
+
+
+def _release_held():
+    _HELD.clear()
+    _HELD_TASK[0] = None
+
+
+def abort_backward_state():
+    """forget what an aborted forward / backward pass left behind in this module (ddp.BucketedGradAllReduce.abort_step)"""
+    _release_held()
+    for ring in _WGRAD_EVENTS.values():
+        ring.clear()
+
+
 WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
 # 1: dgrad reads the weight as stored (`b_nn` form of the 256-column GEMM) and no transposed copies of the frozen weights are kept
 # (-35 GB). Bit-identical to the NT form but currently 0.6-0.85x its rate (192-row tiles only, 64-byte DMA segments, twice the LDS

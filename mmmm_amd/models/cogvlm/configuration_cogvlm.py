@@ -37,4 +37,5 @@ class CogVLMConfig:
         if isinstance(p, int):
             self.vision_config['patch_size'] = (p, p, p)
         self.vision_config['patch_size'] = tuple(self.vision_config['patch_size'])
-        self.vision_config['pos_embed_shape'] = tuple(self.vision_config['pos_embed_shape'])
+        if self.vision_config.get('pos_embed_shape') is not None:      # (else it arrives through `vision_override`, mmmm.py:147-151)
+            self.vision_config['pos_embed_shape'] = tuple(self.vision_config['pos_embed_shape'])

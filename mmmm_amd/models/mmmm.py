@@ -112,6 +112,8 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         """Same keyword surface as the reference's `build` (mmmm.py:82-135). Base weights are loaded from
         `pretrained_model_name_or_path` when it is a local checkpoint directory (checkpoint loaders: SURVEY §8f N3);
         with None the model is randomly initialised (benchmarks / tests: no weights or network in the image)."""
+        if isinstance(vision_override, dict):          # the YAML's mapping (jsonargparse builds the dataclass on the reference)
+            vision_override = VisionArgs(**vision_override)
         self = cls(config or CogVLMConfig(), vision_override=vision_override)
         if pretrained_model_name_or_path is not None:
             from .checkpoint import load_pretrained
@@ -154,6 +156,23 @@ class MMMMForCausalLM(CogVLMForCausalLM):
     def on_load_checkpoint(self, checkpoint: dict):
         checkpoint['state_dict'] = {}
         self.strict_loading = False
+
+    # -- PEFT hooks (luolib.lightning.peft.PeftMixin on the reference: scripts/cli.py:82-88, mmmm.py:154-155) -------------
+    def set_peft_model(self, peft_model) -> None:
+        """called by the CLI right after `get_peft_model(model, lora_config)` (mmmm_amd.peft or a compatible handle)"""
+        object.__setattr__(self, '_peft_model', peft_model)      # (not a submodule: the handle points back at this model)
+
+    @property
+    def peft_model(self):
+        pm = self.__dict__.get('_peft_model')
+        if pm is None:
+            raise AttributeError('no PEFT model attached: call set_peft_model(get_peft_model(model, lora_config)) first (scripts/cli.py:82-85)')
+        return pm
+
+    def load_default_adapter(self, ckpt_dir):
+        """mmmm.py:154-155: the adapter saved next to a training checkpoint (`<ckpt_dir>/adapter`)"""
+        from pathlib import Path
+        self.peft_model.load_adapter(str(Path(ckpt_dir) / 'adapter'), 'default')
 
     def on_fit_start(self) -> None:
         self.gradient_checkpointing_enable({'use_reentrant': False})
@@ -309,6 +328,10 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         host = batch.get('host') or {}
         ids_src = host['input_ids'] if host.get('input_ids') is not None else input_ids
         ids_host = _HostCopy(ids_src[:, 1:]) if self.sam is not None else None
+        # the reference logs `train/token-lm/{bop,eop}_loss` only when such a target exists (mmmm.py:333-341: `if token_mask.any()`,
+        # a device->host synchronisation there); here the labels' host copy answers that without one
+        lab_src = host['labels'] if host.get('labels') is not None else vlm_inputs.get('labels')
+        labels_host = _HostCopy(lab_src) if (self.sam is not None and lab_src is not None) else None
         offs_host = None
         offs_src = host.get('index_offsets') if host.get('index_offsets') is not None else batch.get('index_offsets')
         if self.sam is not None and offs_src is not None:
@@ -329,11 +352,12 @@ class MMMMForCausalLM(CogVLMForCausalLM):
         logs = {'train/loss': loss, 'train/lm_loss': out.loss, 'train/vg_loss': vg_loss, **_add_prefix(vg_log, 'train/vg')}
         # per-token CE on the <p> / </p> targets: the unweighted row CE is already a by-product of the fused lm_head+CE
         with torch.no_grad():
+            lab_h = labels_host.get() if labels_host is not None else None
             for name, tid in (('bop', self.tokenizer.bop_token_id), ('eop', self.tokenizer.eop_token_id)):
+                if lab_h is not None and not bool((lab_h == tid).any()):
+                    continue                      # no such target in this batch: the reference omits the key
                 m = out.row_labels == tid
-                n = m.sum()
-                logs[f'train/token-lm/{name}_loss'] = (out.row_ce * m).sum() / n.clamp_min(1)
-                logs[f'train/token-lm/{name}_count'] = n
+                logs[f'train/token-lm/{name}_loss'] = (out.row_ce * m).sum() / m.sum().clamp_min(1)
         self.log_dict(logs)
         return loss
 

@@ -80,3 +80,27 @@ def apply_lora(model: nn.Module, cfg: LoraConfig, target_modules: list[str] | No
             p.requires_grad_(True)
     model.lora_target_modules, model.lora_modules_to_save = list(target_modules), list(modules_to_save)
     return model
+
+
+def instantiate(spec, *, remap=(('mmmm.', 'mmmm_amd.'),), overrides=None, path: str = ''):
+    """Resolve a `{class_path, init_args}` mapping of the reference's YAML configs (conf/phase-*/model.yaml) the way jsonargparse
+    does for the LightningCLI: import `class_path` (with the package prefix remapped onto this package), instantiate nested specs
+    depth first, call it with `init_args`. `overrides(path, class_path, init_args) -> init_args` lets the caller edit the
+    arguments of any node (tests null the checkpoint paths and shrink the widths). Lightning / jsonargparse are not in the image;
+    this is the part of them the drop-in needs."""
+    import importlib
+    if isinstance(spec, dict) and 'class_path' in spec:
+        cp = spec['class_path']
+        for old, new in remap:
+            if cp.startswith(old):
+                cp = new + cp[len(old):]
+                break
+        args = {k: instantiate(v, remap=remap, overrides=overrides, path=f'{path}.{k}' if path else k)
+                for k, v in (spec.get('init_args') or {}).items()}
+        if overrides is not None:
+            args = overrides(path, cp, args)
+        mod, _, name = cp.rpartition('.')
+        return getattr(importlib.import_module(mod), name)(**args)
+    if isinstance(spec, dict):
+        return {k: instantiate(v, remap=remap, overrides=overrides, path=f'{path}.{k}' if path else k) for k, v in spec.items()}
+    return spec

@@ -245,3 +245,111 @@ def test_no_weight_decay_parameters_get_their_own_buckets():
     ddp = BucketedGradAllReduce(m.parameters(), world_size=1)
     assert sorted((b.decay, len(b.params)) for b in ddp.buckets) == [(False, 1), (True, 2)]
     assert ddp.buckets[ddp._bucket_of[id(m.gain)]].decay is False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# replica consistency at construction (what DDPStrategy's module wrap does, conf/phase-vg/fit.yaml:11-15)
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    torch.manual_seed(rank)                 # every rank draws DIFFERENT initial weights
+    net = Net()
+    net.b.weight.data = net.b.weight.data.to(torch.bfloat16)       # two dtypes -> two broadcast groups
+    before = net.a.weight.detach().clone()
+    ddp = BucketedGradAllReduce(net.parameters(), bucket_bytes=1024)
+    state = {n: p.detach().float().numpy().copy() for n, p in net.named_parameters() if p.requires_grad}
+    changed = not torch.equal(before, net.a.weight.detach())
+    ddp.assert_replicas_equal()
+    # a rank that drifts is caught
+    caught = False
+    if rank == 1:
+        with torch.no_grad():
+            net.a.bias[3] += 1e-3
+    try:
+        ddp.assert_replicas_equal()
+    except RuntimeError as e:
+        caught = 'diverged' in str(e)
+    # a second backward pass after a bucket was reduced must raise instead of corrupting the sum
+    net2 = Net()
+    ddp2 = BucketedGradAllReduce(net2.parameters(), bucket_bytes=1 << 20)
+    ddp2.zero_grad()
+    net2(torch.randn(3, 16), True).backward()
+    second = False
+    try:
+        net2(torch.randn(3, 16), True).backward()
+    except RuntimeError as e:
+        second = 'one backward pass per finish' in str(e)
+    ddp2.finish()
+    q.put((rank, state, changed, caught, second))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_construction_broadcasts_rank0_parameters_and_checks_replicas():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=100) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = Net()
+    for n, p in ref.named_parameters():
+        if p.requires_grad:
+            want = p.detach().to(torch.bfloat16).float().numpy() if n == 'b.weight' else p.detach().numpy()
+            for r in range(world):
+                assert (got[r][0][n] == want).all(), (r, n)          # everybody holds rank 0's draw, bit for bit
+    assert got[0][1] is False and got[1][1] is True                   # rank 1's weights were overwritten
+    assert all(got[r][2] for r in range(world)), 'a drifted replica must be detected on every rank'
+    assert all(got[r][3] for r in range(world)), 'a second backward pass with collectives on must raise'
+
+
+def test_abort_step_clears_side_accumulators_and_parked_tensors():
+    import mmmm_amd.functional as Fh
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    net = Net()
+    net.a.weight.data = net.a.weight.data.to(torch.bfloat16)
+    net.a.bias.data = net.a.bias.data.to(torch.bfloat16)
+    ddp = BucketedGradAllReduce(net.parameters(), world_size=1)
+    acc = ddp.f32_accumulator(net.a.bias)
+    acc += 3.0                                   # partial sums of a pass that then raised
+    Fh._HELD.append(torch.zeros(4))
+    Fh._HELD_TASK[0] = 12345                     # ... inside graph task 12345, whose final callbacks were dropped
+    for b in ddp.buckets:
+        b.buffer.fill_(1)
+    ddp._ready.add(id(net.a.bias))
+    ddp.abort_step()
+    assert float(acc.abs().sum()) == 0 and not Fh._HELD and Fh._HELD_TASK[0] is None
+    assert all(float(b.buffer.float().abs().sum()) == 0 and b.pending == len(b.params) for b in ddp.buckets) and not ddp._ready
+
+
+def test_parked_tensors_of_a_failed_backward_do_not_leak_into_the_next_pass():
+    """the engine drops its final callbacks when a backward pass raises; the next pass must start from an empty list"""
+    import mmmm_amd.functional as Fh
+
+    class Park(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fail):
+            ctx.fail = fail
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            Fh._hold_until_backward_ends(g)
+            if ctx.fail:
+                raise RuntimeError('boom')
+            return g * 2, None
+
+    Fh._release_held()
+    x = torch.ones(3, requires_grad=True)
+    with pytest.raises(RuntimeError, match='boom'):
+        Park.apply(Park.apply(x, True), False).sum().backward()
+    assert len(Fh._HELD) >= 1                    # the raised pass never ran its callback
+    Park.apply(Park.apply(x, False), False).sum().backward()
+    assert not Fh._HELD and Fh._HELD_TASK[0] is None

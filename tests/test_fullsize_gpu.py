@@ -6,7 +6,8 @@ batch 2 to keep the test short): the oracle cannot run this size, so parity is c
   * replay: the same step twice from the same state gives the same loss to 2e-6 (usually bit-identical; dropout masks are a pure function of
     (seed, step, site, element); the only order-dependent sums of the forward are the fp32-atomic split-K products of the
     hyper-network MLPs in the heads). Gradients: the backward contains order-dependent fp32 atomics
-    (ATen's trilinear-upsample / gather backward in the heads: 1e-7 relative), and a random-init network of this depth is
+    (the split-K weight gradients and the norm layers' column sums in the heads: 1e-7 relative; the trilinear up-sampling backward
+    is a deterministic gather since round 2, upsample.hip), and a random-init network of this depth is
     chaotic in backward — every attention layer with saturated random-init softmax amplifies the noise ~100x (measured with
     tools/debug_replay.py: 0 at lm_head, 5e-7 at vg_proj, 6e-5 in the last decoder MLP, 2e-3 one attention layer further
     down, 1e-2 .. 5e-2 through the ViT, where |grad| reaches 1e10). The tight comparison is therefore made upstream of the

@@ -154,15 +154,17 @@ def test_sam_parameter_gradients_through_the_bucket_path_match_oracle(dev):
         sd = {f'sam.{k}': v.requires_grad_(v.is_floating_point()) for k, v in oracle_state(sam).items()}
         ref = O.sam_forward(sd, _sam_cfg(False), 'sam', images, patch, prompts)
         sum(m.square().mean() for m in ref).backward()
-        checked = 0
+        checked, worst = 0, (0.0, '')
         for name, p in sam.named_parameters():
             gr = sd[f'sam.{name}'].grad
             if not p.requires_grad or gr is None or gr.norm() < 1e-7:     # (k_proj.bias: softmax is shift-invariant, gradient == 0)
                 continue
             assert p.grad is not None, name
             assert rel(p.grad, 2 * gr) < 5e-4, (name, rel(p.grad, 2 * gr))
+            worst = max(worst, (rel(p.grad, 2 * gr), name))
             checked += 1
         assert checked > 40
+        print(f'[unfrozen SAM parameter gradients vs oracle] worst relative error {worst[0]:.2e} at {worst[1]} over {checked} tensors')
     finally:
         ddp.remove()
         for p in sam.parameters():

@@ -207,6 +207,17 @@ def test_f13_training_step_bf16_true_vs_reference(dev):
     batch = MyPrecision().convert_input(_to(f8['batch'], dev))
     loss = m.training_step(batch)
     loss.backward()
+    assert set(m.logged) == set(f8['logged']) == set(r16['logged'])          # exactly the reference's keys (mmmm.py:333-351)
+    # ... and a batch without <p> / </p> targets omits the token-lm keys as the reference does (`if token_mask.any()`)
+    nb = {**batch, 'vlm_inputs': {**batch['vlm_inputs'], 'labels': torch.where(
+        (batch['vlm_inputs']['labels'] == m.tokenizer.bop_token_id) | (batch['vlm_inputs']['labels'] == m.tokenizer.eop_token_id),
+        torch.full_like(batch['vlm_inputs']['labels'], -100), batch['vlm_inputs']['labels'])}, 'host': None}
+    kept = dict(m.logged)
+    m.logged.clear()
+    m.training_step(nb)
+    assert set(m.logged) == {k for k in f8['logged'] if 'token-lm' not in k}
+    m.logged.clear()
+    m.logged.update(kept)
     for k, ref16 in r16['logged'].items():
         if not torch.is_tensor(ref16) or not ref16.is_floating_point():
             if k in m.logged:
