@@ -297,6 +297,24 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
                       const int32_t* nrows_dev, float alpha, float drop_p, uint64_t drop_seed, void* workspace,
                       int64_t workspace_bytes, void* stream);
 
+/* A batch of up to VM_TN_GROUP_MAX independent LoRA factor gradients in ONE launch (the weight gradients a transformer layer's
+ * backward produces: peft lora.Linear backward of modeling_cogvlm.py:44-56,87-98,243-245 / visual.py:93-123). Item i:
+ *   out (+)= alpha * sum over rows m in its range of drop(W)[m][c] * S[m][n]        (W [M, C] wide, S [M, 64]; bf16)
+ * stored as out[c][n] (transpose_out == 0: dB [C, 64]) or out[n][c] (transpose_out == 1: dA [64, C]); `out` is ALWAYS accumulated
+ * into (a zeroed or partially filled gradient slot), bf16 (one rounding per call) or fp32. Row range: all M rows, or with
+ * counts_dev the routed segment `segment` (0: [0, counts[0]), 1: [counts[0], counts[1]), other: [0, counts[1])).
+ * One workgroup per 64 columns of one item walks all of the item's rows: no partial sums, no atomics — deterministic.
+ * `block0` is filled in by the call. C % 8 == 0, ldw % 8 == 0, lds % 8 == 0. */
+#define VM_TN_GROUP_MAX 24
+typedef struct {
+  const void* W; int64_t ldw; int32_t C; int32_t M;
+  const void* S; int64_t lds;
+  void* out; int64_t ldo; int32_t out_f32; int32_t transpose_out;
+  const int32_t* counts_dev; int32_t segment; int32_t block0;
+  float alpha; float drop_p; uint64_t seed;
+} vm_tn_group_item;
+int vm_tn_skinny_group_bf16(const vm_tn_group_item* items_host, int n, void* stream);
+
 /* A table of independent small transposes in ONE launch: desc_dev holds n records of six int64
  * {src ptr, dst ptr, rows, cols, ld_src, ld_dst}; dst[c, r] = src[r, c]. Used to refresh the K-contiguous copies of
  * every LoRA factor (peft lora_A/lora_B of scripts/cli.py:82-85) once per optimizer step instead of once per use.

@@ -49,8 +49,13 @@ constexpr int DN_STAGE = 2 * DN_BM * ROWB;     // x tile + A tile
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
                                            int col0, int cols_total, char* tile, int wave, int lane);
 
-__global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * DN_STAGE];
+// STAGES = depth of the LDS-DMA ring (STAGES - 1 K-tiles of loads in flight per workgroup). 2: 64 KiB, two workgroups per CU — the
+// K-split form, whose grid has more workgroups than CUs. 4: 128 KiB, one workgroup per CU — the single-pass form of a short K
+// ([6280 x 1792]: 99 workgroups of 14 K-tiles; with one tile in flight each of them paid the full memory latency 14 times in a
+// row: 19-23 us for 22.5 MB in situ).
+template <int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const DownP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES * DN_STAGE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int M = p.M, split = p.split;
@@ -80,13 +85,14 @@ __global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int64_t m = row0 + wave * 16 + frow;
 
-  auto stage = [&](int kt, int buf) {
+  auto stage = [&](int kt, int buf) {        // K-tiles past the range stage zero rows: every wave issues 8 DMA instructions per call
     char* sx = smem + buf * DN_STAGE;
     char* sa = sx + DN_BM * ROWB;
+    const bool live = kt < kt1;
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
-      stage_rows(p.x, p.ldx, row0 + 32 * hlf, max(0, nrows - 32 * hlf), kt * 128, p.K, sx + hlf * 32 * ROWB, wave, lane);
-      stage_rows(A, p.lda, 32 * hlf, 32, kt * 128, p.K, sa + hlf * 32 * ROWB, wave, lane);
+      stage_rows(p.x, p.ldx, row0 + 32 * hlf, live ? max(0, nrows - 32 * hlf) : 0, kt * 128, p.K, sx + hlf * 32 * ROWB, wave, lane);
+      stage_rows(A, p.lda, 32 * hlf, live ? 32 : 0, kt * 128, p.K, sa + hlf * 32 * ROWB, wave, lane);
     }
   };
 
@@ -94,12 +100,16 @@ __global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  stage(kt0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < STAGES - 1; ++i) stage(kt0 + i, i);
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+    const int buf = (kt - kt0) % STAGES;
+    // this wave's part of K-tile `kt` has landed (STAGES - 2 tiles stay in flight: 8 DMA instructions per wave and tile) ...
+    if (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // ... everybody's has, and tile kt - 1 has been consumed: its buffer is free
+    stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
     const char* sx = smem + buf * DN_STAGE;
     const char* sa = sx + DN_BM * ROWB;
 #pragma unroll
@@ -118,9 +128,8 @@ __global__ __launch_bounds__(256, 2) void lora_down_k(const DownP p) {
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[i], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-row tail stages
   // D[row = r][col = m_local]: lane holds r = 16 i + 4 fq + 0..3 for row m
   if (wave * 16 + frow >= nrows) return;
   if (drop) {
@@ -459,6 +468,139 @@ __global__ __launch_bounds__(256) void tn_reduce_k(const float* __restrict__ ws,
     if (c0 + cb + e < C) o[e] = Elem<TO>::st(tile[n][cb + e] + (accumulate ? Elem<TO>::ld(o[e]) : 0.f));
 }
 
+
+// ============================================================================ vm_tn_skinny_group (a batch of LoRA factor gradients)
+// Up to VM_TN_GROUP_MAX independent factor gradients (vm_tn_group_item: out += alpha * W^T S over a row range) in ONE launch:
+// the backward of a transformer layer produces 8 (ViT-E) or 20 (decoder: two experts) of them, each a 28-240 workgroup problem
+// when launched alone — too small for 256 CUs without row splits, and with row splits each needs a second launch that reduces
+// the fp32 partials (round 2: 16 launches per ViT layer, 236 us of kernel time). Here a workgroup owns 64 columns of ONE item and
+// walks ALL of its rows (no partials, no reduce launch, no atomics: deterministic), and the items of a whole layer together are
+// 700+ equally long workgroups. The result is added into `out` (a gradient-bucket slot) with one rounding.
+struct GroupP { int n; vm_tn_group_item it[VM_TN_GROUP_MAX]; };
+constexpr int GR_STAGES = 3;          // ring depth: 2 steps of loads in flight per workgroup, 48 KiB -> 3 workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void tn_group_k(const GroupP p) {
+  __shared__ __attribute__((aligned(16))) char smem[GR_STAGES * SK_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // item of this block: the table is tiny and wave-uniform (kernel arguments live in SGPRs / the scalar cache)
+  int idx = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.n; ++i) idx = ((int)blockIdx.x >= p.it[i].block0) ? i : idx;
+  const vm_tn_group_item& q = p.it[idx];
+  const unsigned short* W = (const unsigned short*)q.W;
+  const unsigned short* S = (const unsigned short*)q.S;
+  const int C = q.C;
+  const int c0 = ((int)blockIdx.x - q.block0) * 64;
+  const int wc = wave >> 1, wn = wave & 1;
+  int rb = 0, re = q.M;
+  if (q.counts_dev) {
+    const int k0 = __builtin_amdgcn_readfirstlane(q.counts_dev[0]);
+    const int k1 = min(q.M, __builtin_amdgcn_readfirstlane(q.counts_dev[1]));
+    if (q.segment == 0) { rb = 0; re = min(k0, k1); }
+    else if (q.segment == 1) { rb = min(k0, k1); re = k1; }
+    else { rb = 0; re = k1; }
+  }
+  const int steps = (re - rb + 31) / 32;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int c_end = min(C, c0 + 64);
+  auto stage = [&](int step, int buf) {      // steps past the range stage zero rows (uniform DMA count for s_waitcnt)
+    const int r0 = rb + step * 32;
+    const int valid = step < steps ? min(32, re - r0) : 0;
+    char* sw = smem + buf * SK_STAGE;
+    stage_rows(W, q.ldw, r0, valid, c0, c_end, sw, wave, lane);
+    stage_rows(S, q.lds, r0, valid, 0, 64, sw + 32 * ROWB, wave, lane);
+  };
+  const bool drop = q.drop_p > 0.f;
+  const unsigned thr = vm_drop_threshold(q.drop_p);
+#pragma unroll
+  for (int i = 0; i < GR_STAGES - 1; ++i) stage(i, i);
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st % GR_STAGES;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's part of step `st` has landed (one step stays in flight)
+    __syncthreads();                                        // ... everybody's has, and step st-1 has been consumed
+    stage(st + GR_STAGES - 1, (buf + GR_STAGES - 1) % GR_STAGES);
+    char* sw = smem + buf * SK_STAGE;
+    const char* ss = sw + 32 * ROWB;
+    if (drop) {
+      const int r0 = rb + st * 32;
+      const int row = tid >> 3, chunk = tid & 7;          // 32 rows x 8 chunks of 8 columns
+      const int col = c0 + chunk * 8;
+      char* addr = sw + tile_off(row, chunk);
+      u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
+      const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)C + (uint64_t)col;
+      const uint64_t h0 = vm_hash4(q.seed, e >> 2), h1 = vm_hash4(q.seed, (e >> 2) + 1);
+      vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
+      *reinterpret_cast<u16x8_t*>(addr) = v;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sw, 16 * ks, wc, lane), frag_tr(ss, 16 * ks, wn, lane), acc, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-row tail stages before the LDS is reused
+  __syncthreads();
+  // the 64 x 64 fp32 tile through LDS (pitch 65 floats), then every thread adds 16 consecutive outputs of one output row
+  float* tile = reinterpret_cast<float*>(smem);
+  const int h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[(wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 65 + wn * 32 + (lane & 31)] = acc[r];
+  __syncthreads();
+  const float alpha = q.alpha;
+  const int orow = tid >> 2, o16 = (tid & 3) * 16;          // output row (c or n), 16 consecutive entries of it
+  if (!q.transpose_out) {
+    // out[c0 + orow][o16 .. o16 + 15]
+    if (c0 + orow >= C) return;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = alpha * tile[orow * 65 + o16 + e];
+    if (q.out_f32) {
+      float* o = (float*)q.out + (int64_t)(c0 + orow) * q.ldo + o16;
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        f32x4_t t = *reinterpret_cast<f32x4_t*>(o + e);
+        t += (f32x4_t){v[e], v[e + 1], v[e + 2], v[e + 3]};
+        *reinterpret_cast<f32x4_t*>(o + e) = t;
+      }
+    } else {
+      unsigned short* o = (unsigned short*)q.out + (int64_t)(c0 + orow) * q.ldo + o16;
+#pragma unroll
+      for (int e = 0; e < 16; e += 8) {
+        u16x8_t t = *reinterpret_cast<u16x8_t*>(o + e);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[e + k]);
+        *reinterpret_cast<u16x8_t*>(o + e) = t;
+      }
+    }
+  } else {
+    // out[orow][c0 + o16 .. + 15]: the transposed tile read column-wise out of LDS
+    const int cbase = c0 + o16;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = alpha * tile[(o16 + e) * 65 + orow];
+    const bool full = cbase + 16 <= C && (q.ldo % 8) == 0;
+    if (q.out_f32) {
+      float* o = (float*)q.out + (int64_t)orow * q.ldo + cbase;
+      for (int e = 0; e < 16; ++e) if (cbase + e < C) o[e] += v[e];
+    } else {
+      unsigned short* o = (unsigned short*)q.out + (int64_t)orow * q.ldo + cbase;
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 8) {
+          u16x8_t t = *reinterpret_cast<u16x8_t*>(o + e);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[e + k]);
+          *reinterpret_cast<u16x8_t*>(o + e) = t;
+        }
+      } else {
+        for (int e = 0; e < 16; ++e) if (cbase + e < C) o[e] = f2bf(bf2f(o[e]) + v[e]);
+      }
+    }
+  }
+}
+
 // row splits: about 1.5 workgroups per CU, at least 8 steps each; the fp32 partials then stay a fraction of the input
 static int tn_skinny_bc(int C) { return C >= 6144 ? 128 : 64; }
 static int tn_skinny_splits(int M, int C) {
@@ -521,7 +663,16 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   const int grid = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  hipLaunchKernelGGL(lora_down_k, dim3(grid, p.ksplits), dim3(256), 0, (hipStream_t)stream, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)lora_down_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DN_STAGE) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DN_STAGE) != hipSuccess) return VM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  static const int deep = [] { const char* e = getenv("VM_LORA_DOWN_DEEP"); return e ? atoi(e) : 1; }();
+  // deep ring when the grid cannot give a CU two workgroups anyway
+  if (deep && grid * p.ksplits <= 320) hipLaunchKernelGGL(lora_down_k<4>, dim3(grid, p.ksplits), dim3(256), 4 * DN_STAGE, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(lora_down_k<2>, dim3(grid, p.ksplits), dim3(256), 2 * DN_STAGE, (hipStream_t)stream, p);
   if (p.ksplits > 1)
     hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)p.ws, p.t, p.ldt, M, p.ksplits, counts_dev);
@@ -599,6 +750,34 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
     hipLaunchKernelGGL(tn_reduce_k<float>, rg, dim3(256), 0, (hipStream_t)stream, (const float*)p.ws, p.c_pad, C, p.splits,
                        (float*)out, (float*)out1, ldo, transpose_out, accumulate, alpha);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * (double)M * C * 64.0);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_tn_skinny_group_bf16(const vm_tn_group_item* items_host, int n, void* stream) {
+  if (!items_host || n < 0 || n > VM_TN_GROUP_MAX) return VM_ERR_BAD_ARG;
+  if (n == 0) return VM_OK;
+  GroupP p;
+  p.n = n;
+  int blocks = 0;
+  double flops = 0;
+  for (int i = 0; i < n; ++i) {
+    vm_tn_group_item q = items_host[i];
+    if (!q.W || !q.S || !q.out || q.C <= 0 || q.M < 0) return VM_ERR_BAD_ARG;
+    if (q.ldw % 8 || q.lds % 8 || q.C % 8) return VM_ERR_BAD_ARG;
+    if (q.out_f32 ? (!q.transpose_out && q.ldo % 4) : (!q.transpose_out && q.ldo % 8)) return VM_ERR_BAD_ARG;
+    if ((int64_t)32 * q.ldw * 2 + 256 >= (1ll << 31) || (int64_t)32 * q.lds * 2 + 256 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
+    if (!q.counts_dev) q.segment = -1;
+    if (q.drop_p > 0.f) q.alpha /= 1.0f - q.drop_p;          // the kernel only masks; inverted-dropout scale folded here
+    q.block0 = blocks;
+    blocks += (q.C + 63) / 64;
+    flops += 2.0 * (double)q.M * q.C * 64.0;
+    p.it[i] = q;
+  }
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_LORA, stream, &tok);
+  hipLaunchKernelGGL(tn_group_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  vm_prof_end_(VM_PROF_LORA, stream, tok, flops);
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

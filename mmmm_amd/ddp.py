@@ -213,6 +213,9 @@ class BucketedGradAllReduce:
         self._launch_ready()
 
     def _launch(self, b: _Bucket):
+        if b.buffer.is_cuda:
+            from . import functional as Fh
+            Fh.flush_wgrad_queue()          # factor gradients still queued for a grouped launch belong to this (or an earlier) bucket
         if b.buffer.is_cuda:       # the launching stream must see every producer stream's gradient writes
             cur = torch.cuda.current_stream(b.buffer.device)
             for st in b.streams:
@@ -239,6 +242,9 @@ class BucketedGradAllReduce:
         (zero-filled slots for unused parameters), waits for the collectives, averages, and joins every stream that wrote a
         gradient in this step — also when there is no collective (one rank), where nothing else orders the side-stream
         weight-gradient kernels before the optimizer."""
+        if self.buckets and self.buckets[0].buffer.is_cuda:
+            from . import functional as Fh
+            Fh.flush_wgrad_queue()
         while self._next < len(self.buckets):
             self._launch(self.buckets[self._next])
             self._next += 1

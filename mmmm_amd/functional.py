@@ -148,6 +148,8 @@ def abort_backward_state():
     _release_held()
     for ring in _WGRAD_EVENTS.values():
         ring.clear()
+    _WGRAD_QUEUE.clear()
+    _WGRAD_QUEUE_STATE[0] = _WGRAD_QUEUE_STATE[1] = None
 
 
 WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '1') == '1'
@@ -203,6 +205,54 @@ def _off_critical_path(fn, device, keep_alive):
         cur.wait_event(ring.pop(0))
 
 
+# LoRA factor gradients are not launched one by one: they are queued and go out as ONE grouped launch per ~layer
+# (kernels.tn_skinny_group / vm_tn_skinny_group_bf16): a transformer layer's backward produces 8 (ViT-E) or 20 (decoder, two experts)
+# of them, each too small for the chip alone. 0: one launch (+ its reduce launch) per factor as in round 2 (A/B measurements).
+WGRAD_GROUP = os.environ.get('VM_WGRAD_GROUP', '1') == '1'
+_WGRAD_QUEUE: list = []           # [(item for kernels.tn_skinny_group, param, ready callback)]
+_WGRAD_QUEUE_STATE = [None, None]     # graph-task id of the backward pass the queue belongs to, stream its operands were produced on
+
+
+def _queue_wgrad(param, ready, W, S, transpose_out, counts, seg, alpha, drop_p, seed):
+    task = torch._C._current_graph_task_id()
+    st = torch.cuda.current_stream(W.device)
+    if task != _WGRAD_QUEUE_STATE[0] or st != _WGRAD_QUEUE_STATE[1]:
+        flush_wgrad_queue()
+        if task != _WGRAD_QUEUE_STATE[0] and task >= 0:
+            # whatever is still queued when this backward pass ends goes out then (callers may read .grad right after backward())
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_queue)
+        _WGRAD_QUEUE_STATE[0], _WGRAD_QUEUE_STATE[1] = task, st
+    _WGRAD_QUEUE.append(((W, S, param.grad, transpose_out, counts, seg, alpha, drop_p, seed), param, ready))
+    if len(_WGRAD_QUEUE) >= hip.TN_GROUP_MAX:
+        flush_wgrad_queue()
+
+
+def flush_wgrad_queue():
+    """launch the queued factor gradients (on the stream their operands were produced on) and tell the gradient buckets. Called
+    when the queue is full, before a gradient bucket is reduced (ddp._launch / finish) and at the end of every backward pass."""
+    if not _WGRAD_QUEUE:
+        return
+    items = _WGRAD_QUEUE[:]
+    _WGRAD_QUEUE.clear()
+    st = _WGRAD_QUEUE_STATE[1]
+    cur = torch.cuda.current_stream(st.device)
+    if cur != st:
+        torch.cuda.set_stream(st)
+    try:
+        K.tn_skinny_group([it for it, _, _ in items])
+        for _, p, ready in items:
+            ready(p)
+    finally:
+        if cur != st:
+            torch.cuda.set_stream(cur)
+
+
+def _direct_slot(param):
+    """the parameter's gradient lives in a flat reduction bucket the kernels may accumulate into (ddp.BucketedGradAllReduce)"""
+    return (getattr(param, '_vm_grad_ready', None) is not None and param.grad is not None
+            and param.grad.dtype in (torch.bfloat16, torch.float32) and param.grad.stride(-1) == 1)
+
+
 def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
     """gradient of one LoRA factor through the skinny row-contraction kernel. When the parameter's gradient lives in a
     flat reduction bucket (ddp.BucketedGradAllReduce tags it with `_vm_grad_ready`) the kernel accumulates straight into
@@ -211,8 +261,12 @@ def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
         if transpose_out:
             return K.gemm_tn(S, W, counts=counts, segment=seg, alpha=scale, drop_p=drop_p, drop_seed=seed)
         return K.gemm_tn(W, S, counts=counts, segment=seg, alpha=scale)
-    ready = getattr(param, '_vm_grad_ready', None)
-    if ready is not None and param.grad is not None and param.grad.dtype in (torch.bfloat16, torch.float32):
+    if _direct_slot(param):
+        ready = param._vm_grad_ready
+        if WGRAD_GROUP:
+            _queue_wgrad(param, ready, W, S, transpose_out, counts, seg, scale, drop_p, seed)
+            return None
+
         def run():
             K.tn_skinny(W, S, transpose_out=transpose_out, out=param.grad, accumulate=True, counts=counts, segment=seg, alpha=scale,
                         drop_p=drop_p, drop_seed=seed)
@@ -227,10 +281,14 @@ def _lora_wgrad_pair(params, W, S, transpose_out, counts, scale, drop_p, seed):
     """both experts of a gated linear in ONE launch (segment 0 -> params[0], segment 1 -> params[1]); returns the pair of
     gradients for autograd (None where the kernel accumulated straight into the bucket view)."""
     p0, p1 = params
-    r0, r1 = getattr(p0, '_vm_grad_ready', None), getattr(p1, '_vm_grad_ready', None)
-    direct = (r0 is not None and r1 is not None and p0.grad is not None and p1.grad is not None and p0.grad.dtype == p1.grad.dtype
-              and p0.grad.dtype in (torch.bfloat16, torch.float32) and p0.grad.stride() == p1.grad.stride())
+    direct = _direct_slot(p0) and _direct_slot(p1) and p0.grad.dtype == p1.grad.dtype and p0.grad.stride() == p1.grad.stride()
+    if direct and WGRAD_GROUP:
+        _queue_wgrad(p0, p0._vm_grad_ready, W, S, transpose_out, counts, 0, scale, drop_p, seed)
+        _queue_wgrad(p1, p1._vm_grad_ready, W, S, transpose_out, counts, 1, scale, drop_p, seed)
+        return None, None
     if direct:
+        r0, r1 = p0._vm_grad_ready, p1._vm_grad_ready
+
         def run():
             K.tn_skinny(W, S, transpose_out=transpose_out, out=(p0.grad, p1.grad), accumulate=True, counts=counts, segment=2,
                         alpha=scale, drop_p=drop_p, drop_seed=seed)

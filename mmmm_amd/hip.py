@@ -83,6 +83,20 @@ class AttnF32Args(C.Structure):
     ]
 
 
+TN_GROUP_MAX = 24
+
+
+class TnGroupItem(C.Structure):
+    """vm_tn_group_item (include/vividmed_hip.h)"""
+    _fields_ = [
+        ('W', C.c_void_p), ('ldw', C.c_int64), ('C', C.c_int32), ('M', C.c_int32),
+        ('S', C.c_void_p), ('lds', C.c_int64),
+        ('out', C.c_void_p), ('ldo', C.c_int64), ('out_f32', C.c_int32), ('transpose_out', C.c_int32),
+        ('counts_dev', C.c_void_p), ('segment', C.c_int32), ('block0', C.c_int32),
+        ('alpha', C.c_float), ('drop_p', C.c_float), ('seed', C.c_uint64),
+    ]
+
+
 def declared_symbols() -> list[str]:
     """Every function name declared in include/vividmed_hip.h."""
     text = HEADER_PATH.read_text()

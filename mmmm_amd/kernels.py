@@ -325,6 +325,25 @@ def tn_skinny(W: torch.Tensor, S: torch.Tensor, *, transpose_out: bool, out=None
     return out
 
 
+def tn_skinny_group(items: list) -> None:
+    """A batch of LoRA factor gradients in one launch (vm_tn_skinny_group_bf16). Each item is a tuple
+    (W [M, C] bf16, S [M, 64] bf16, out, transpose_out, counts | None, segment, alpha, drop_p, drop_seed): `out` ([C, 64], or [64, C]
+    when transpose_out; bf16 or fp32) is ACCUMULATED into. Deterministic (one workgroup per 64 output columns walks all rows)."""
+    for i in range(0, len(items), hip.TN_GROUP_MAX):
+        chunk = items[i:i + hip.TN_GROUP_MAX]
+        arr = (hip.TnGroupItem * len(chunk))()
+        for q, (W, S, out, transpose_out, counts, segment, alpha, drop_p, seed) in zip(arr, chunk):
+            M, Cw = W.shape
+            assert S.shape == (M, 64) and W.dtype == torch.bfloat16 and S.dtype == torch.bfloat16 and W.stride(1) == 1 and S.stride(1) == 1
+            assert out.shape == ((64, Cw) if transpose_out else (Cw, 64)) and out.stride(1) == 1 and out.dtype in (torch.bfloat16, torch.float32)
+            q.W, q.ldw, q.C, q.M = ptr(W), _ld(W), Cw, M
+            q.S, q.lds = ptr(S), _ld(S)
+            q.out, q.ldo, q.out_f32, q.transpose_out = ptr(out), _ld(out), int(out.dtype == torch.float32), int(transpose_out)
+            q.counts_dev, q.segment = ptr(counts), segment if counts is not None else -1
+            q.alpha, q.drop_p, q.seed = alpha, drop_p, seed & 0xFFFFFFFFFFFFFFFF
+        hip.call('vm_tn_skinny_group_bf16', C.addressof(arr), len(chunk), stream())
+
+
 # ------------------------------------------------------------------ norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, nrows: torch.Tensor | None = None):
     x = _c(x)

@@ -690,6 +690,47 @@ def test_tn_skinny_segments(dev, K):
     assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
 
 
+def test_tn_skinny_group(dev, K):
+    """a batch of LoRA factor gradients in one launch (vm_tn_skinny_group_bf16): every item against a torch fp32 contraction — both
+    output orientations, bf16 and fp32 slots, accumulation into non-zero slots, routed row segments from device counts (an empty
+    one included), a ragged column count, the dropout mask of the forward, more items than one launch holds; deterministic"""
+    g = torch.Generator(device=dev).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    counts = torch.tensor([200, 517, 0, 0], dtype=torch.int32, device=dev)
+    empty = torch.tensor([0, 0, 0, 0], dtype=torch.int32, device=dev)
+    specs = []          # (M, C, transpose_out, out dtype, counts, segment, alpha, drop_p)
+    for i in range(28):
+        specs.append(((785, 640, 1000, 333)[i % 4], (1792, 136, 64, 4096, 264)[i % 5], bool(i & 1), (torch.bfloat16, torch.float32)[(i >> 1) & 1],
+                      None, -1, (1.0, 0.5)[i % 2], 0.1 if i % 3 == 2 else 0.0))
+    specs += [(640, 256, False, torch.float32, counts, 0, 1.0, 0.0), (640, 256, True, torch.float32, counts, 1, 0.5, 0.0),
+              (640, 256, True, torch.bfloat16, counts, 1, 1.0, 0.1), (640, 128, False, torch.float32, empty, 1, 1.0, 0.0)]
+    items, refs, outs = [], [], []
+    for j, (M, Cw, tr, dt, cnt, seg, alpha, p) in enumerate(specs):
+        W, S = rn(M, Cw).bfloat16(), rn(M, 64).bfloat16()
+        base = rn(64, Cw) if tr else rn(Cw, 64)
+        out = base.to(dt).clone()
+        lo, hi = 0, M
+        if cnt is not None:
+            c0, c1 = int(cnt[0]), int(cnt[1])
+            lo, hi = (0, c0) if seg == 0 else (c0, c1)
+        Wm = W.float()
+        if p > 0:
+            Wm = Wm * (K.dropout(torch.ones_like(W), p, 1000 + j) != 0).float() / (1 - p)
+        r = alpha * (Wm[lo:hi].T @ S.float()[lo:hi])
+        refs.append(out.float() + (r.T if tr else r))
+        outs.append(out)
+        items.append((W, S, out, tr, cnt, seg, alpha, p, 1000 + j))
+    K.tn_skinny_group(items)
+    for j, (o, r) in enumerate(zip(outs, refs)):
+        assert rel_err(o, r) < (6e-3 if o.dtype == torch.bfloat16 else 2e-5), (j, specs[j], rel_err(o, r))
+    # same inputs, same bits
+    outs2 = [torch.zeros_like(o) for o in outs]
+    outs3 = [torch.zeros_like(o) for o in outs]
+    K.tn_skinny_group([(it[0], it[1], o, *it[3:]) for it, o in zip(items, outs2)])
+    K.tn_skinny_group([(it[0], it[1], o, *it[3:]) for it, o in zip(items, outs3)])
+    assert all(torch.equal(a, b) for a, b in zip(outs2, outs3))
+
+
 def test_gemm_tn_segments_and_dropout(dev, K):
     M, P, Q = 517, 64, 256
     X = torch.randn(640, P, device=dev).bfloat16()
