@@ -34,7 +34,19 @@ struct DownP {
   const int32_t* counts_dev; int split;
   float drop_p; uint64_t seed;
   float* ws; int ksplits;                   // fp32 partials [ksplits][M][64] when ksplits > 1
+  // fused producer modes (vm_lora_down_fused): x is COMPUTED from `x` / `x2` (same leading dimension) element by element, written to
+  // `y` once, and projected in the same pass
+  const unsigned short* x2; unsigned short* y; int64_t ldy;
 };
+// MODE of lora_down_k: how the projected operand comes about
+//   0  x as stored                                       (vm_lora_down)
+//   1  y = gelu(x)                  [visual.py:129 MLP.forward: fc2(act(fc1(x)))]        t = drop(y) A^T
+//   2  y = x2 * gelu'(x)            [its backward: x = pre-activation, x2 = dy]          t = y B       (u of fc1's LoRA path)
+//   3  y = bf16(silu(x)) * x2       [modeling_cogvlm.py:55 down_proj(act(gate) * up)]    t = drop(y) A^T
+#define VM_LD_PLAIN 0
+#define VM_LD_GELU 1
+#define VM_LD_GELU_BWD 2
+#define VM_LD_SILU_MUL 3
 
 // Streaming skinny GEMM: a workgroup owns 64 rows x one K range. x (the HBM stream) and the 64 x K factor slice are
 // staged per 128-wide K-tile through LDS-DMA (whole 256-byte row segments, 2 stages, 2 workgroups per CU), so the factor
@@ -44,7 +56,6 @@ struct DownP {
 // K is split over blockIdx.y to fill the chip; partial sums go to an fp32 workspace and are reduced in a FIXED order by
 // lora_reduce_k (deterministic, no atomics).
 constexpr int DN_BM = 64;
-constexpr int DN_STAGE = 2 * DN_BM * ROWB;     // x tile + A tile
 
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
                                            int col0, int cols_total, char* tile, int wave, int lane);
@@ -53,8 +64,10 @@ __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t l
 // K-split form, whose grid has more workgroups than CUs. 4: 128 KiB, one workgroup per CU — the single-pass form of a short K
 // ([6280 x 1792]: 99 workgroups of 14 K-tiles; with one tile in flight each of them paid the full memory latency 14 times in a
 // row: 19-23 us for 22.5 MB in situ).
-template <int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const DownP p) {
+template <int STAGES, int MODE = VM_LD_PLAIN>
+__global__ __launch_bounds__(256, (STAGES == 2 && MODE < 2) ? 2 : 1) void lora_down_k(const DownP p) {
+  constexpr int NIN = MODE >= 2 ? 2 : 1;                               // element-wise inputs staged per K-tile
+  constexpr int DN_STAGE = (NIN + 1) * DN_BM * ROWB;                   // input tile(s) + factor tile
   extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES * DN_STAGE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,14 +100,17 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
 
   auto stage = [&](int kt, int buf) {        // K-tiles past the range stage zero rows: every wave issues 8 DMA instructions per call
     char* sx = smem + buf * DN_STAGE;
-    char* sa = sx + DN_BM * ROWB;
+    char* sa = sx + NIN * DN_BM * ROWB;
     const bool live = kt < kt1;
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
       stage_rows(p.x, p.ldx, row0 + 32 * hlf, live ? max(0, nrows - 32 * hlf) : 0, kt * 128, p.K, sx + hlf * 32 * ROWB, wave, lane);
+      if (NIN == 2)
+        stage_rows(p.x2, p.ldx, row0 + 32 * hlf, live ? max(0, nrows - 32 * hlf) : 0, kt * 128, p.K, sx + (DN_BM + hlf * 32) * ROWB, wave, lane);
       stage_rows(A, p.lda, 32 * hlf, live ? 32 : 0, kt * 128, p.K, sa + hlf * 32 * ROWB, wave, lane);
     }
   };
+  constexpr int DMA_PER_TILE = 4 * (NIN + 1);        // DMA instructions per wave and K-tile
 
   f32x4_t acc[4];
 #pragma unroll
@@ -105,16 +121,34 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) % STAGES;
     // this wave's part of K-tile `kt` has landed (STAGES - 2 tiles stay in flight: 8 DMA instructions per wave and tile) ...
+    // (the element-wise stores of the fused modes are vector-memory operations too: they are younger than the loads waited for)
+    static_assert(STAGES == 2 || MODE == VM_LD_PLAIN, "the counted waits of the deep ring assume loads only");
     if (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                       // ... everybody's has, and tile kt - 1 has been consumed: its buffer is free
     stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
     const char* sx = smem + buf * DN_STAGE;
-    const char* sa = sx + DN_BM * ROWB;
+    const char* sa = sx + NIN * DN_BM * ROWB;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       u16x8_t xv = *reinterpret_cast<const u16x8_t*>(sx + tile_off(wave * 16 + frow, 4 * s + fq));
+      if (MODE != VM_LD_PLAIN) {
+        // the operand is produced here, element by element with the standalone kernels' rounding (rowwise.hip ew_k), and written once
+        u16x8_t bv;
+        if (NIN == 2) bv = *reinterpret_cast<const u16x8_t*>(sx + DN_BM * ROWB + tile_off(wave * 16 + frow, 4 * s + fq));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(xv[e]);
+          float r;
+          if (MODE == VM_LD_GELU) r = gelu_erf(f);
+          else if (MODE == VM_LD_GELU_BWD) r = gelu_erf_grad(f) * bf2f(bv[e]);
+          else r = bf2f(f2bf(f / (1.0f + __expf(-f)))) * bf2f(bv[e]);
+          xv[e] = f2bf(r);
+        }
+        const int kc = kt * 128 + 32 * s + 8 * fq;
+        if (wave * 16 + frow < nrows && kc + 8 <= p.K) *reinterpret_cast<u16x8_t*>(p.y + m * p.ldy + kc) = xv;
+      }
       if (drop) {
         const int kk = kt * 128 + 32 * s + 8 * fq;
         const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
@@ -129,6 +163,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
       }
     }
   }
+  (void)DMA_PER_TILE;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-row tail stages
   // D[row = r][col = m_local]: lane holds r = 16 i + 4 fq + 0..3 for row m
   if (wave * 16 + frow >= nrows) return;
@@ -640,10 +675,12 @@ int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host) {
   return VM_OK;
 }
 
-int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
-                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
-                 void* workspace, int64_t workspace_bytes, void* stream) {
+static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx, void* y, int64_t ldy, const void* A0, const void* A1,
+                            int64_t lda, void* t, int64_t ldt, int M, int K, int R, const int32_t* counts_dev, int split, float drop_p,
+                            uint64_t drop_seed, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !A0 || !t) return VM_ERR_BAD_ARG;
+  if (mode != VM_LD_PLAIN && (!y || ldy % 8)) return VM_ERR_BAD_ARG;
+  if ((mode == VM_LD_GELU_BWD || mode == VM_LD_SILU_MUL) && !x2) return VM_ERR_BAD_ARG;
   if (M <= 0) return VM_OK;
   if (R != 64 || K % 8 || K < 8 || ldx % 8 || lda % 8 || ldt % 4) return VM_ERR_UNSUPPORTED;
   if ((int64_t)32 * ldx * 2 + 256 >= (1ll << 31) || (int64_t)32 * lda * 2 + 256 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
@@ -651,6 +688,7 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   if (segmented && !A1) return VM_ERR_BAD_ARG;
   DownP p;
   p.x = (const unsigned short*)x; p.ldx = ldx;
+  p.x2 = (const unsigned short*)x2; p.y = (unsigned short*)y; p.ldy = ldy;
   p.A0 = (const unsigned short*)A0; p.A1 = (const unsigned short*)(A1 ? A1 : A0); p.lda = lda;
   p.t = (unsigned short*)t; p.ldt = ldt;
   p.M = M; p.K = K;
@@ -661,24 +699,53 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   p.ws = (float*)workspace;
   if (p.ksplits > 1 && (!workspace || workspace_bytes < (int64_t)p.ksplits * M * 64 * 4)) p.ksplits = 1;   // no workspace: single pass
   const int grid = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
-  void* tok = nullptr;
-  vm_prof_begin_(VM_PROF_LORA, stream, &tok);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lora_down_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DN_STAGE) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * DN_STAGE) != hipSuccess) return VM_ERR_LAUNCH;
+    const int one = DN_BM * ROWB;
+    if (hipFuncSetAttribute((const void*)lora_down_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * one) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU_BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess ||
+        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess)
+      return VM_ERR_LAUNCH;
     attr_set = true;
   }
-  static const int deep = [] { const char* e = getenv("VM_LORA_DOWN_DEEP"); return e ? atoi(e) : 1; }();
-  // deep ring when the grid cannot give a CU two workgroups anyway
-  if (deep && grid * p.ksplits <= 320) hipLaunchKernelGGL(lora_down_k<4>, dim3(grid, p.ksplits), dim3(256), 4 * DN_STAGE, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(lora_down_k<2>, dim3(grid, p.ksplits), dim3(256), 2 * DN_STAGE, (hipStream_t)stream, p);
+  // VM_LORA_DOWN_DEEP=1: four-stage ring for single-pass grids (measured neutral inside the step: 320.3 vs 320.5 ms, A B A B)
+  static const int deep = [] { const char* e = getenv("VM_LORA_DOWN_DEEP"); return e ? atoi(e) : 0; }();
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_LORA, stream, &tok);
+  const dim3 g(grid, p.ksplits), b(256);
+  const int one = DN_BM * ROWB;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case VM_LD_GELU: hipLaunchKernelGGL((lora_down_k<2, VM_LD_GELU>), g, b, 2 * 2 * one, st, p); break;
+    case VM_LD_GELU_BWD: hipLaunchKernelGGL((lora_down_k<2, VM_LD_GELU_BWD>), g, b, 2 * 3 * one, st, p); break;
+    case VM_LD_SILU_MUL: hipLaunchKernelGGL((lora_down_k<2, VM_LD_SILU_MUL>), g, b, 2 * 3 * one, st, p); break;
+    default:
+      if (deep && grid * p.ksplits <= 320) hipLaunchKernelGGL((lora_down_k<4>), g, b, 4 * 2 * one, st, p);
+      else hipLaunchKernelGGL((lora_down_k<2>), g, b, 2 * 2 * one, st, p);
+  }
   if (p.ksplits > 1)
     hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)p.ws, p.t, p.ldt, M, p.ksplits, counts_dev);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * M * 64.0 * K);
   VM_LAUNCH_CHECK();
   return VM_OK;
+}
+
+int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
+                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
+  return lora_down_launch(VM_LD_PLAIN, x, nullptr, ldx, nullptr, 0, A0, A1, lda, t, ldt, M, K, R, counts_dev, split, drop_p, drop_seed,
+                          workspace, workspace_bytes, stream);
+}
+
+int vm_lora_down_fused(int mode, const void* x, const void* x2, int64_t ldx, void* y, int64_t ldy, const void* A0, const void* A1,
+                       int64_t lda, void* t, int64_t ldt, int M, int K, int R, const int32_t* counts_dev, int split, float drop_p,
+                       uint64_t drop_seed, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (mode != VM_LD_GELU && mode != VM_LD_GELU_BWD && mode != VM_LD_SILU_MUL) return VM_ERR_BAD_ARG;
+  return lora_down_launch(mode, x, x2, ldx, y, ldy, A0, A1, lda, t, ldt, M, K, R, counts_dev, split, drop_p, drop_seed, workspace,
+                          workspace_bytes, stream);
 }
 
 int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ldy, int Q, void* C, int64_t ldc,

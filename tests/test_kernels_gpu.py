@@ -690,6 +690,34 @@ def test_tn_skinny_segments(dev, K):
     assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
 
 
+@pytest.mark.parametrize('M,Kd', [(785, 1792), (300, 15360), (64, 136)])
+def test_lora_down_fused_producers(dev, K, M, Kd):
+    """the element-wise op in front of a LoRA linear fused with the linear's rank-64 projection (vm_lora_down_fused): the activation is
+    bit-identical to the standalone element-wise kernel's and the projection to vm_lora_down of that activation (same kernel, same
+    summation order), for GELU, its backward, and SiLU * up with two routed experts"""
+    g = torch.Generator(device=dev).manual_seed(M + Kd)
+    h = torch.randn(M, Kd, device=dev, generator=g).bfloat16()
+    dy = torch.randn(M, Kd, device=dev, generator=g).bfloat16()
+    A = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16()
+    A1 = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16()
+    for p_, seed in ((0.0, 0), (0.1, 77)):
+        y, t = K.lora_down_fused(K.LD_GELU, h, None, A, drop_p=p_, drop_seed=seed)
+        ref = K.gelu(h)
+        assert torch.equal(y, ref) and torch.equal(t, K.lora_down(ref, A, drop_p=p_, drop_seed=seed))
+    y, t = K.lora_down_fused(K.LD_GELU_BWD, h, dy, A)
+    ref = K.gelu_bwd(h, dy)
+    assert torch.equal(y, ref) and torch.equal(t, K.lora_down(ref, A))
+    counts = torch.tensor([M // 3, M - 5, 0, 0], dtype=torch.int32, device=dev)
+    y, t = K.lora_down_fused(K.LD_SILU_MUL, h, dy, A, A1, counts=counts, drop_p=0.05, drop_seed=5)
+    ref = K.silu_mul(h, dy)
+    n = M - 5
+    assert torch.equal(y[:n], ref[:n])
+    assert torch.equal(t[:n], K.lora_down(ref, A, A1, counts=counts, drop_p=0.05, drop_seed=5)[:n])
+    # against plain torch as well (the standalone kernels have their own tests; this guards the wiring)
+    tt = torch.nn.functional.gelu(h.float()).bfloat16().float() @ A.float().T
+    assert rel_err(K.lora_down_fused(K.LD_GELU, h, None, A)[1], tt) < 6e-3
+
+
 def test_tn_skinny_group(dev, K):
     """a batch of LoRA factor gradients in one launch (vm_tn_skinny_group_bf16): every item against a torch fp32 contraction — both
     output orientations, bf16 and fp32 slots, accumulation into non-zero slots, routed row segments from device counts (an empty
