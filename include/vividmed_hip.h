@@ -292,6 +292,15 @@ int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
 int vm_transpose_colsum(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype, float* colsum_accum,
                         void* stream);
 
+/* fp32 weight gradient in TN form: C[P, Q] += X[M, P]^T Y[M, Q] with X (= dy) and Y (= x) row-major as autograd holds them — the
+ * weight gradients of the unfrozen fp32 islands (every nn.Linear under segvol/modeling, mmmm.py:137-138; README Stage 1 / 3:
+ * --model.freeze_sam false) without transposed copies of the activations. Split-bf16 arithmetic as vm_gemm_f32 (f32_split 2: three
+ * products, 3: six, 0: the process default; the exact mode 1 is not available here: VM_ERR_UNSUPPORTED). C is ACCUMULATED into
+ * (a gradient-bucket slot): plain read-modify-write when one workgroup per tile walks all rows, fp32 atomics when the rows are split.
+ * colsum (optional, fp32 [P]): += the column sums of X, i.e. the bias gradient. P % 8 == 0, Q % 8 == 0, ldx % 4 == 0, ldy % 4 == 0. */
+int vm_gemm_tn_f32(const float* X, int64_t ldx, int P, const float* Y, int64_t ldy, int Q, float* C, int64_t ldc, int M, float* colsum,
+                   int f32_split, void* stream);
+
 /* LoRA factor gradients: row contraction of a wide streamed operand W [M, C] with a rank-64 operand S [M, 64]
  * (peft lora.Linear backward: dB = s * dy^T t, dA = s * u^T drop(x); functional._Linear.backward).
  *   transpose_out == 0: out[c][n] (C rows, 64 columns, ldo)   = [accumulate ? out : 0] + alpha * sum_m W[m][c] S[m][n]

@@ -531,6 +531,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
 
 int vm_gemm_bf16(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 2); }
 int vm_gemm_f32(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 4); }
+int vm_gemm_f32_mode_get_(void) { return f32_mode(); }      /* internal: the process default as the other translation units see it */
 int vm_gemm_f32_mode(int mode) {
   if (mode != 0 && mode != 2 && mode != 3) return VM_ERR_BAD_ARG;
   f32_mode() = mode;

@@ -55,6 +55,10 @@ struct DownP {
 // v_mfma_f32_16x16x32_bf16; the dropout mask is applied to the x fragment in registers, once per element.
 // K is split over blockIdx.y to fill the chip; partial sums go to an fp32 workspace and are reduced in a FIXED order by
 // lora_reduce_k (deterministic, no atomics).
+// [r3] measured and NOT kept: (a) a 16-row single-pass form for K <= 4096 (four waves own 16 output columns each, 393 / 229
+// workgroups, no reduce launch): 317.5 vs 317.8 ms at K <= 2048, 319.2 / 319.7 vs 317.8 ms at K <= 4096 — the factor is re-read per
+// 16 rows; (b) a four-stage DMA ring for the single-pass grids: 320.3 vs 320.5 ms. Kept: always split K (4 x 99 workgroups + reduce
+// at K = 1792 instead of 99 workgroups): -0.9 ms.
 constexpr int DN_BM = 64;
 
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
@@ -340,6 +344,151 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(const TnP p) {
     }
 }
 
+// ============================================================================ vm_gemm_tn_f32 (fp32 weight gradients, TN form)
+// C[P, Q] += X[M, P]^T Y[M, Q] for fp32 operands as they sit in HBM (dW = dy^T x of every unfrozen nn.Linear of the SAM / iSAM
+// islands): round 2 transposed BOTH operands into K-contiguous copies for the NT kernel (618 transpose launches per step).
+// Split-bf16 arithmetic as vm_gemm_f32 (NS = 2: three products, NS = 3: six), but the split happens ONCE, in the threads that
+// stage a tile: 32-row steps are loaded row-major with 16-byte loads, split into NS bf16 planes and written to LDS in the
+// transposed-read image of vm_tile.hpp; the MFMA operands are then ds_read_b64_tr_b16 fragments exactly as in gemm_tn_k.
+// Tile 64 (P) x 128 (Q), one workgroup walks all rows when the grid fills the chip (no atomics: C += is a plain
+// read-modify-write of an exclusively owned tile), else rows are split over blockIdx.y with fp32 atomics whose access shape is
+// the full-rate one (a 32x32 accumulator register = two 128-byte row segments per wave instruction).
+// `colsum`: the column sums of X (the bias gradient) are accumulated by the workgroups of the first Q tile from the values they
+// stage anyway.
+struct TnF32P {
+  const float* X; int64_t ldx; int P;
+  const float* Y; int64_t ldy; int Q;
+  float* C; int64_t ldc;
+  float* colsum;
+  int M, splits, tiles_q;
+};
+
+template <int NS>
+__device__ __forceinline__ void split_store8(const f32x4_t& a, const f32x4_t& b, char* planes, int plane_bytes, int off) {
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u16x8_t h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = f2bf(x[e]);
+    *reinterpret_cast<u16x8_t*>(planes + s * plane_bytes + off) = h;
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] -= bf2f(h[e]);
+    }
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_k(const TnF32P p) {
+  constexpr int PLANE = 32 * ROWB;                 // one bf16 plane of a 32-row step (128 columns wide; X uses the first 64)
+  constexpr int STAGE = 2 * NS * PLANE;            // X planes, then Y planes
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 * STAGE
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave >> 1, wq = wave & 1;
+  const int tp = blockIdx.x / p.tiles_q, tq = blockIdx.x % p.tiles_q;
+  const int p0 = tp * 64, q0 = tq * 128;
+  const int total_steps = (p.M + 31) / 32;
+  const int per = (total_steps + p.splits - 1) / p.splits;
+  const int s_begin = blockIdx.y * per, s_end = min(total_steps, s_begin + per);
+  if (s_begin >= s_end) return;
+
+  f32x16_t acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  // staging map: thread -> row tid >> 3 of the step, 8 consecutive X columns and 16 consecutive Y columns
+  const int srow = tid >> 3, sg = tid & 7;
+  const int xcol = p0 + sg * 8, ycol = q0 + sg * 16;
+  const bool xin = xcol + 8 <= p.P;                          // (P % 8 == 0, Q % 8 == 0: whole 8-column groups)
+  const bool yin0 = ycol + 8 <= p.Q, yin1 = ycol + 16 <= p.Q;
+  f32x4_t rx[2], ry[4];
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int step) {
+    const int m = step * 32 + srow;
+    const bool rin = m < p.M;
+    const float* xr = p.X + (int64_t)m * p.ldx + xcol;
+    const float* yr = p.Y + (int64_t)m * p.ldy + ycol;
+    rx[0] = (rin && xin) ? *reinterpret_cast<const f32x4_t*>(xr) : zero4;
+    rx[1] = (rin && xin) ? *reinterpret_cast<const f32x4_t*>(xr + 4) : zero4;
+    ry[0] = (rin && yin0) ? *reinterpret_cast<const f32x4_t*>(yr) : zero4;
+    ry[1] = (rin && yin0) ? *reinterpret_cast<const f32x4_t*>(yr + 4) : zero4;
+    ry[2] = (rin && yin1) ? *reinterpret_cast<const f32x4_t*>(yr + 8) : zero4;
+    ry[3] = (rin && yin1) ? *reinterpret_cast<const f32x4_t*>(yr + 12) : zero4;
+  };
+  const bool do_colsum = p.colsum != nullptr && tq == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto split_write = [&](int buf) {
+    char* sx = smem + buf * STAGE;
+    char* sy = sx + NS * PLANE;
+    split_store8<NS>(rx[0], rx[1], sx, PLANE, tile_off(srow, sg));
+    split_store8<NS>(ry[0], ry[1], sy, PLANE, tile_off(srow, 2 * sg));
+    split_store8<NS>(ry[2], ry[3], sy, PLANE, tile_off(srow, 2 * sg + 1));
+    if (do_colsum) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bsum[e] += rx[0][e]; bsum[4 + e] += rx[1][e]; }
+    }
+  };
+
+  load(s_begin);
+  split_write(0);
+  __syncthreads();
+  for (int st = s_begin; st < s_end; ++st) {
+    const int buf = (st - s_begin) & 1;
+    const bool more = st + 1 < s_end;
+    if (more) load(st + 1);                                   // global loads in flight under the MFMAs of this step
+    const char* sx = smem + buf * STAGE;
+    const char* sy = sx + NS * PLANE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t xa[NS], yb[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        xa[s] = frag_tr(sx + s * PLANE, 16 * ks, wp, lane);
+        yb[s][0] = frag_tr(sy + s * PLANE, 16 * ks, 2 * wq, lane);
+        yb[s][1] = frag_tr(sy + s * PLANE, 16 * ks, 2 * wq + 1, lane);
+      }
+      // cross terms x_s y_t with s + t < NS, smallest first
+#pragma unroll
+      for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+        for (int sw = 0; sw <= d; ++sw)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[sw], yb[d - sw][b], acc[b], 0, 0, 0);
+    }
+    if (more) split_write(buf ^ 1);
+    __syncthreads();
+  }
+  // D[i = p_local][j = q_local]: col = lane & 31 -> q, rows (r&3) + 8 (r>>2) + 4 h -> p
+  const int h = lane >> 5;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int qq = q0 + wq * 64 + b * 32 + (lane & 31);
+    if (qq >= p.Q) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pp = p0 + wp * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (pp >= p.P) continue;
+      float* c = p.C + (int64_t)pp * p.ldc + qq;
+      if (p.splits > 1) atomicAdd(c, acc[b][r]);
+      else *c += acc[b][r];
+    }
+  }
+  if (do_colsum) {
+    // the 8 row-threads of a wave that share a column group: lanes sg, sg + 8, ..., sg + 56
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = bsum[e];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (lane < 8 && xcol + e < p.P) atomicAdd(p.colsum + xcol + e, v);
+    }
+  }
+}
+
 // ============================================================================ vm_tn_skinny (LoRA factor gradients)
 // O[c][n] = sum_m W[m][c] * S[m][n] with a WIDE streamed operand W [M, C] and a rank-64 operand S [M, 64]:
 //   dB[N, 64] = s * dy^T t      (W = dy, S = t)            -> out[c][n]
@@ -512,10 +661,21 @@ __global__ __launch_bounds__(256) void tn_reduce_k(const float* __restrict__ ws,
 // walks ALL of its rows (no partials, no reduce launch, no atomics: deterministic), and the items of a whole layer together are
 // 700+ equally long workgroups. The result is added into `out` (a gradient-bucket slot) with one rounding.
 struct GroupP { int n; vm_tn_group_item it[VM_TN_GROUP_MAX]; };
-constexpr int GR_STAGES = 3;          // ring depth: 2 steps of loads in flight per workgroup, 48 KiB -> 3 workgroups per CU
+// A workgroup owns GR_BC = 256 columns of one item (wave w: columns 64 w .. 64 w + 63, both 32-wide halves of the 64 n). What bounds
+// these kernels is the bytes a CU can take in through LDS-DMA (~25 GB/s per CU, 6.4 TB/s for the chip: MI355X_MICROARCH.md 'ldsdma-fill';
+// the first form of this kernel, 64 columns per workgroup, moved a 128-byte row of the rank-64 operand for every 128 bytes of W and ran at
+// exactly half that rate: 584 us for three ViT-E layers): with 256 columns the rank-64 operand is a quarter of the W bytes.
+constexpr int GR_BC = 256;
+constexpr int GR_STAGE_BYTES = 3 * 32 * ROWB;      // W columns 0..127, W columns 128..255, S (the first 128 bytes of each row are used)
+#ifndef VM_GR_STAGES
+#define VM_GR_STAGES 2
+#endif
+// ring depth. 2 (48 KiB, three workgroups per CU = 768 slots): the items of three ViT-E layers are 528 workgroups, and with the 512 slots
+// of the three-stage ring the 16 left over ran a second round alone (533 us per launch; the chip-wide HBM rate would allow ~330)
+constexpr int GR_STAGES = VM_GR_STAGES;
 
-__global__ __launch_bounds__(256, 2) void tn_group_k(const GroupP p) {
-  __shared__ __attribute__((aligned(16))) char smem[GR_STAGES * SK_STAGE];
+__global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const GroupP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // GR_STAGES * GR_STAGE_BYTES
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // item of this block: the table is tiny and wave-uniform (kernel arguments live in SGPRs / the scalar cache)
@@ -526,8 +686,7 @@ __global__ __launch_bounds__(256, 2) void tn_group_k(const GroupP p) {
   const unsigned short* W = (const unsigned short*)q.W;
   const unsigned short* S = (const unsigned short*)q.S;
   const int C = q.C;
-  const int c0 = ((int)blockIdx.x - q.block0) * 64;
-  const int wc = wave >> 1, wn = wave & 1;
+  const int c0 = ((int)blockIdx.x - q.block0) * GR_BC;
   int rb = 0, re = q.M;
   if (q.counts_dev) {
     const int k0 = __builtin_amdgcn_readfirstlane(q.counts_dev[0]);
@@ -537,16 +696,20 @@ __global__ __launch_bounds__(256, 2) void tn_group_k(const GroupP p) {
     else { rb = 0; re = k1; }
   }
   const int steps = (re - rb + 31) / 32;
-  f32x16_t acc;
+  f32x16_t acc[2][2];          // [32-column block of the wave's 64][32-wide half of n]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int c_end = min(C, c0 + 64);
-  auto stage = [&](int step, int buf) {      // steps past the range stage zero rows (uniform DMA count for s_waitcnt)
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  auto stage = [&](int step, int buf) {      // steps past the range stage zero rows (uniform DMA count for s_waitcnt: 6 per wave)
     const int r0 = rb + step * 32;
     const int valid = step < steps ? min(32, re - r0) : 0;
-    char* sw = smem + buf * SK_STAGE;
-    stage_rows(W, q.ldw, r0, valid, c0, c_end, sw, wave, lane);
-    stage_rows(S, q.lds, r0, valid, 0, 64, sw + 32 * ROWB, wave, lane);
+    char* sw = smem + buf * GR_STAGE_BYTES;
+    stage_rows(W, q.ldw, r0, valid, c0, C, sw, wave, lane);
+    stage_rows(W, q.ldw, r0, valid, c0 + 128, C, sw + 32 * ROWB, wave, lane);
+    stage_rows(S, q.lds, r0, valid, 0, 64, sw + 2 * 32 * ROWB, wave, lane);
   };
   const bool drop = q.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(q.drop_p);
@@ -554,83 +717,107 @@ __global__ __launch_bounds__(256, 2) void tn_group_k(const GroupP p) {
   for (int i = 0; i < GR_STAGES - 1; ++i) stage(i, i);
   for (int st = 0; st < steps; ++st) {
     const int buf = st % GR_STAGES;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's part of step `st` has landed (one step stays in flight)
+    if (GR_STAGES == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this wave's part of step `st` has landed (one step stays in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // ... everybody's has, and step st-1 has been consumed
     stage(st + GR_STAGES - 1, (buf + GR_STAGES - 1) % GR_STAGES);
-    char* sw = smem + buf * SK_STAGE;
-    const char* ss = sw + 32 * ROWB;
+    char* sw = smem + buf * GR_STAGE_BYTES;
+    const char* ss = sw + 2 * 32 * ROWB;
     if (drop) {
       const int r0 = rb + st * 32;
-      const int row = tid >> 3, chunk = tid & 7;          // 32 rows x 8 chunks of 8 columns
-      const int col = c0 + chunk * 8;
-      char* addr = sw + tile_off(row, chunk);
-      u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
-      const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)C + (uint64_t)col;
-      const uint64_t h0 = vm_hash4(q.seed, e >> 2), h1 = vm_hash4(q.seed, (e >> 2) + 1);
-      vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
-      *reinterpret_cast<u16x8_t*>(addr) = v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {               // 32 rows x 32 chunks of 8 columns: four per thread
+        const int cc = tid + i * 256;
+        const int row = cc >> 5, ch = cc & 31;    // chunk ch of the 256-column row: sub-tile ch >> 4, chunk ch & 15 inside it
+        const int col = c0 + ch * 8;
+        char* addr = sw + (ch >> 4) * 32 * ROWB + tile_off(row, ch & 15);
+        u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
+        const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)C + (uint64_t)col;
+        const uint64_t h0 = vm_hash4(q.seed, e >> 2), h1 = vm_hash4(q.seed, (e >> 2) + 1);
+        vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
+        *reinterpret_cast<u16x8_t*>(addr) = v;
+      }
       __syncthreads();
     }
+    const char* swv = sw + (wave >> 1) * 32 * ROWB;        // the 128-column sub-tile that holds this wave's 64 columns
+    const int cb = 2 * (wave & 1);                         // ... as 32-column blocks cb, cb + 1 of it
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(sw, 16 * ks, wc, lane), frag_tr(ss, 16 * ks, wn, lane), acc, 0, 0, 0);
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t s0 = frag_tr(ss, 16 * ks, 0, lane), s1 = frag_tr(ss, 16 * ks, 1, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8_t wa = frag_tr(swv, 16 * ks, cb + a, lane);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, s0, acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, s1, acc[a][1], 0, 0, 0);
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-row tail stages before the LDS is reused
   __syncthreads();
-  // the 64 x 64 fp32 tile through LDS (pitch 65 floats), then every thread adds 16 consecutive outputs of one output row
-  float* tile = reinterpret_cast<float*>(smem);
+  // every wave parks one 32 (c) x 64 (n) half of its fp32 tile at a time in its own 8.1 KiB of LDS (pitch 65 floats) and adds
+  // consecutive outputs of one output row per lane (same-wave LDS round trips: the compiler orders the reads behind the writes)
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 65);
   const int h = lane >> 5;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) tile[(wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 65 + wn * 32 + (lane & 31)] = acc[r];
-  __syncthreads();
   const float alpha = q.alpha;
-  const int orow = tid >> 2, o16 = (tid & 3) * 16;          // output row (c or n), 16 consecutive entries of it
-  if (!q.transpose_out) {
-    // out[c0 + orow][o16 .. o16 + 15]
-    if (c0 + orow >= C) return;
-    float v[16];
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {
+    const int cw0 = c0 + wave * 64 + a * 32;                // first column of this half
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = alpha * tile[orow * 65 + o16 + e];
-    if (q.out_f32) {
-      float* o = (float*)q.out + (int64_t)(c0 + orow) * q.ldo + o16;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) {
-        f32x4_t t = *reinterpret_cast<f32x4_t*>(o + e);
-        t += (f32x4_t){v[e], v[e + 1], v[e + 2], v[e + 3]};
-        *reinterpret_cast<f32x4_t*>(o + e) = t;
-      }
-    } else {
-      unsigned short* o = (unsigned short*)q.out + (int64_t)(c0 + orow) * q.ldo + o16;
+      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 65 + b * 32 + (lane & 31)] = (a ? acc[1][b][r] : acc[0][b][r]);
+    if (!q.transpose_out) {
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        // out[cw0 + orow][o16 .. o16 + 15]
+        const int orow = pass * 16 + (lane >> 2), o16 = (lane & 3) * 16;
+        if (cw0 + orow >= C) continue;
+        float v[16];
 #pragma unroll
-      for (int e = 0; e < 16; e += 8) {
-        u16x8_t t = *reinterpret_cast<u16x8_t*>(o + e);
+        for (int e = 0; e < 16; ++e) v[e] = alpha * tile[orow * 65 + o16 + e];
+        if (q.out_f32) {
+          float* o = (float*)q.out + (int64_t)(cw0 + orow) * q.ldo + o16;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[e + k]);
-        *reinterpret_cast<u16x8_t*>(o + e) = t;
-      }
-    }
-  } else {
-    // out[orow][c0 + o16 .. + 15]: the transposed tile read column-wise out of LDS
-    const int cbase = c0 + o16;
-    float v[16];
+          for (int e = 0; e < 16; e += 4) {
+            f32x4_t t = *reinterpret_cast<f32x4_t*>(o + e);
+            t += (f32x4_t){v[e], v[e + 1], v[e + 2], v[e + 3]};
+            *reinterpret_cast<f32x4_t*>(o + e) = t;
+          }
+        } else {
+          unsigned short* o = (unsigned short*)q.out + (int64_t)(cw0 + orow) * q.ldo + o16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = alpha * tile[(o16 + e) * 65 + orow];
-    const bool full = cbase + 16 <= C && (q.ldo % 8) == 0;
-    if (q.out_f32) {
-      float* o = (float*)q.out + (int64_t)orow * q.ldo + cbase;
-      for (int e = 0; e < 16; ++e) if (cbase + e < C) o[e] += v[e];
-    } else {
-      unsigned short* o = (unsigned short*)q.out + (int64_t)orow * q.ldo + cbase;
-      if (full) {
+          for (int e = 0; e < 16; e += 8) {
+            u16x8_t t = *reinterpret_cast<u16x8_t*>(o + e);
 #pragma unroll
-        for (int e = 0; e < 16; e += 8) {
-          u16x8_t t = *reinterpret_cast<u16x8_t*>(o + e);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[e + k]);
-          *reinterpret_cast<u16x8_t*>(o + e) = t;
+            for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[e + k]);
+            *reinterpret_cast<u16x8_t*>(o + e) = t;
+          }
         }
-      } else {
-        for (int e = 0; e < 16; ++e) if (cbase + e < C) o[e] = f2bf(bf2f(o[e]) + v[e]);
+      }
+    } else {
+#pragma unroll 1
+      for (int pass = 0; pass < 4; ++pass) {
+        // out[orow = n][cw0 + o8 .. + 7]: the transposed tile read column-wise out of LDS
+        const int orow = pass * 16 + (lane >> 2), o8 = (lane & 3) * 8;
+        const int cbase = cw0 + o8;
+        if (cbase >= C) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = alpha * tile[(o8 + e) * 65 + orow];
+        if (q.out_f32) {
+          float* o = (float*)q.out + (int64_t)orow * q.ldo + cbase;
+          for (int e = 0; e < 8; ++e) if (cbase + e < C) o[e] += v[e];
+        } else {
+          unsigned short* o = (unsigned short*)q.out + (int64_t)orow * q.ldo + cbase;
+          if (cbase + 8 <= C && (q.ldo % 8) == 0) {
+            u16x8_t t = *reinterpret_cast<u16x8_t*>(o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = f2bf(bf2f(t[k]) + v[k]);
+            *reinterpret_cast<u16x8_t*>(o) = t;
+          } else {
+            for (int e = 0; e < 8; ++e) if (cbase + e < C) o[e] = f2bf(bf2f(o[e]) + v[e]);
+          }
+        }
       }
     }
   }
@@ -661,8 +848,10 @@ extern "C" {
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
-  if (kt <= 16 && m_tiles >= 64) return 1;
-  int want = (384 + m_tiles - 1) / m_tiles;
+  static const int kt1 = [] { const char* e = getenv("VM_LORA_KT1"); return e ? atoi(e) : 0; }();
+  static const int target = [] { const char* e = getenv("VM_LORA_WANT"); return e ? atoi(e) : 384; }();
+  if (kt <= kt1 && m_tiles >= 64) return 1;
+  int want = (target + m_tiles - 1) / m_tiles;
   want = max(1, min(want, kt / 2));
   const int per = (kt + want - 1) / want;
   return (kt + per - 1) / per;
@@ -837,14 +1026,56 @@ int vm_tn_skinny_group_bf16(const vm_tn_group_item* items_host, int n, void* str
     if (!q.counts_dev) q.segment = -1;
     if (q.drop_p > 0.f) q.alpha /= 1.0f - q.drop_p;          // the kernel only masks; inverted-dropout scale folded here
     q.block0 = blocks;
-    blocks += (q.C + 63) / 64;
+    blocks += (q.C + GR_BC - 1) / GR_BC;
     flops += 2.0 * (double)q.M * q.C * 64.0;
     p.it[i] = q;
   }
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  hipLaunchKernelGGL(tn_group_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)tn_group_k, hipFuncAttributeMaxDynamicSharedMemorySize, GR_STAGES * GR_STAGE_BYTES) != hipSuccess) return VM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tn_group_k, dim3(blocks), dim3(256), GR_STAGES * GR_STAGE_BYTES, (hipStream_t)stream, p);
   vm_prof_end_(VM_PROF_LORA, stream, tok, flops);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+extern "C" int vm_gemm_f32_mode_get_(void);
+
+int vm_gemm_tn_f32(const float* X, int64_t ldx, int P, const float* Y, int64_t ldy, int Q, float* C, int64_t ldc, int M, float* colsum,
+                   int f32_split, void* stream) {
+  if (!X || !Y || !C) return VM_ERR_BAD_ARG;
+  if (P <= 0 || Q <= 0 || M <= 0) return VM_OK;
+  if (P % 8 || Q % 8 || ldx % 4 || ldy % 4) return VM_ERR_UNSUPPORTED;
+  if (f32_split < 0 || f32_split > 3) return VM_ERR_BAD_ARG;
+  const int mode = f32_split == 0 ? vm_gemm_f32_mode_get_() : f32_split;
+  if (mode != 2 && mode != 3) return VM_ERR_UNSUPPORTED;          // the exact f32 MFMA chain exists in the NT kernel only
+  TnF32P p;
+  p.X = X; p.ldx = ldx; p.P = P; p.Y = Y; p.ldy = ldy; p.Q = Q; p.C = C; p.ldc = ldc; p.M = M; p.colsum = colsum;
+  const int tiles_p = (P + 63) / 64;
+  p.tiles_q = (Q + 127) / 128;
+  const int tiles = tiles_p * p.tiles_q;
+  const int steps = (M + 31) / 32;
+  // one workgroup per tile walks all rows when the tiles alone give every CU about a workgroup; otherwise split the rows
+  static const int target = [] { const char* e = getenv("VM_TN_F32_TARGET"); return e ? atoi(e) : 800; }();
+  int splits = 1;
+  if (tiles < target / 2) splits = max(1, min(steps / 8, (target + tiles - 1) / tiles));
+  p.splits = splits;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_f32_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 2 * 32 * ROWB) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemm_tn_f32_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 3 * 32 * ROWB) != hipSuccess)
+      return VM_ERR_LAUNCH;
+    attr_set = true;
+  }
+  void* tok = nullptr;
+  vm_prof_begin_(VM_PROF_GEMM_F32, stream, &tok);
+  if (mode == 2) hipLaunchKernelGGL(gemm_tn_f32_k<2>, dim3(tiles, splits), dim3(256), 2 * 2 * 2 * 32 * ROWB, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_tn_f32_k<3>, dim3(tiles, splits), dim3(256), 2 * 2 * 3 * 32 * ROWB, (hipStream_t)stream, p);
+  vm_prof_end_(VM_PROF_GEMM_F32, stream, tok, 2.0 * (double)M * P * Q);
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -85,33 +85,42 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_k(
 }
 
 // dw[c] += sum_r dy[r,c] * xhat[r,c] ; db[c] += sum_r dy[r,c]   with xhat = (x - mean[r]) * rstd[r]  (mean == NULL -> 0).
-// Grid: (cols/64 column groups) x (row chunks of 128); lane = column, the 4 waves of a block interleave rows.
+// Grid: (cols / 256 column groups) x (row chunks of 32); a lane owns 4 consecutive columns (8- or 16-byte loads: a wave reads
+// 512 B / 1 KiB of a row per instruction — the first form, one 2-byte column per lane, ran at 2.1 TB/s), the 4 waves of a block
+// interleave rows and are summed through LDS before one atomic per column and block.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_dwdb_k(
     const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ rstd,
     float* __restrict__ dw_accum, float* __restrict__ db_accum, int rows, int cols, const int32_t* nrows_dev) {
-  __shared__ float red[2][4][64];
+  __shared__ float red[2][4][256];
   if (nrows_dev) rows = min(rows, *nrows_dev);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int r0 = blockIdx.y * 128;
-  const int r1 = min(r0 + 128, rows);
-  float aw = 0.f, ab = 0.f;
-  if (c < cols) {
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int r0 = blockIdx.y * 32;
+  const int r1 = min(r0 + 32, rows);
+  float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  typedef T vec4_t __attribute__((ext_vector_type(4)));
+  if (c < cols) {          // (cols % 4 == 0: a lane's four columns are all inside or all outside)
     for (int r = r0 + wid; r < r1; r += 4) {
-      const float g = Elem<T>::ld(dy[(int64_t)r * cols + c]);
-      const float mu = mean ? mean[r] : 0.f;
-      aw += g * ((Elem<T>::ld(x[(int64_t)r * cols + c]) - mu) * rstd[r]);
-      ab += g;
+      const vec4_t gv = *reinterpret_cast<const vec4_t*>(dy + (int64_t)r * cols + c);
+      const vec4_t xv = *reinterpret_cast<const vec4_t*>(x + (int64_t)r * cols + c);
+      const float mu = mean ? mean[r] : 0.f, rs = rstd[r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g = Elem<T>::ld(gv[i]);
+        aw[i] += g * ((Elem<T>::ld(xv[i]) - mu) * rs);
+        ab[i] += g;
+      }
     }
   }
-  red[0][wid][lane] = aw; red[1][wid][lane] = ab;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[0][wid][lane * 4 + i] = aw[i]; red[1][wid][lane * 4 + i] = ab[i]; }
   __syncthreads();
-  if (wid == 0 && c < cols && r0 < rows) {
-    aw = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    ab = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-    if (dw_accum) atomicAdd(dw_accum + c, aw);
-    if (db_accum) atomicAdd(db_accum + c, ab);
+  const int cc = blockIdx.x * 256 + threadIdx.x;          // one column per thread for the final sum
+  if (cc < cols && r0 < rows) {
+    const int t = threadIdx.x;
+    if (dw_accum) atomicAdd(dw_accum + cc, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+    if (db_accum) atomicAdd(db_accum + cc, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
   }
 }
 
@@ -761,7 +770,7 @@ int vm_rmsnorm_bwd_res(const void* x, const void* w, const void* dy, const float
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
-  dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
+  dim3 gridw((cols + 255) / 256, (rows + 31) / 32);
   DISPATCH_DTYPE(dtype,
                  if (dx) hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
                                             (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev, (const T*)dx_add);
@@ -797,7 +806,7 @@ int vm_layernorm_bwd_res(const void* x, const void* w, const void* dy, const flo
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
-  dim3 gridw((cols + 63) / 64, (rows + 127) / 128);
+  dim3 gridw((cols + 255) / 256, (rows + 31) / 32);
   DISPATCH_DTYPE(dtype,
                  if (dx) hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
                                             (const T*)dy, mean, rstd, (T*)dx, rows, cols, (const T*)dx_add);

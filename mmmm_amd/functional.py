@@ -163,6 +163,9 @@ WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '0') == '1'
 # read instructions): the step loses more than the freed memory buys (model-hr-3d: every layer kept, yet 3.47 vs 3.59 images/s;
 # phase-vg-448 445 vs 359 ms), so the default stays the NT dgrad on resident transposes.
 NN_DGRAD = os.environ.get('VM_NN_DGRAD', '0') == '1'
+# fp32 weight gradients of the unfrozen heads through the TN kernel (vm_gemm_tn_f32: no transposed copies of dy and x); 0: round 2's
+# two transposes + NT GEMM (A/B measurements)
+F32_TN_WGRAD = os.environ.get('VM_F32_TN_WGRAD', '1') == '1'
 # 0: ops asked to `fork` (hand their input back for the block's residual) return the input itself, i.e. autograd sums the two gradients of
 # the input with its own element-wise add (A/B measurements)
 FORK = os.environ.get('VM_FORK', '1') == '1'
@@ -440,8 +443,12 @@ class _Linear(Function):
                     fuse_b = bready is not None and b.grad is not None and b.grad.dtype == torch.float32 and b.grad.is_contiguous()
 
                     def run(W=W, wready=wready, b=b, bready=bready, fuse_b=fuse_b):
-                        dyT = K.transpose(dy, pad_to=64, colsum_out=b.grad if fuse_b else None)
-                        K.gemm(dyT, tr(x), out=W.grad, accumulate=True, f32_split=meta.f32_split)
+                        if F32_TN_WGRAD and meta.f32_split != 1 and K.gemm_tn_f32_supported(dy, x, W.grad):
+                            # TN form: dy and x as they are, the bias gradient from the tiles the kernel stages anyway
+                            K.gemm_tn_f32(dy, x, W.grad, colsum_out=b.grad if fuse_b else None, f32_split=meta.f32_split)
+                        else:
+                            dyT = K.transpose(dy, pad_to=64, colsum_out=b.grad if fuse_b else None)
+                            K.gemm(dyT, tr(x), out=W.grad, accumulate=True, f32_split=meta.f32_split)
                         wready(W)
                         if fuse_b:
                             bready(b)

@@ -144,7 +144,12 @@ def lib() -> C.CDLL:
             )
         _lib = C.CDLL(str(LIB_PATH))
         for name, argtypes in _prototypes().items():
-            fn = getattr(_lib, name)
+            try:
+                fn = getattr(_lib, name)
+            except AttributeError:
+                if os.environ.get('VM_LIB_PATH'):      # an older A/B build (tools/build_ref_lib.sh) may lack the newest entry points
+                    continue
+                raise
             fn.restype = C.c_int
             fn.argtypes = argtypes
     return _lib

@@ -308,6 +308,25 @@ def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = N
 VM_F32_ = hip.VM_F32
 
 
+def gemm_tn_f32_supported(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor) -> bool:
+    return (X.dtype == torch.float32 and Y.dtype == torch.float32 and out.dtype == torch.float32 and X.dim() == 2 and Y.dim() == 2
+            and X.shape[0] == Y.shape[0] and X.stride(1) == 1 and Y.stride(1) == 1 and out.stride(1) == 1
+            and X.shape[1] % 8 == 0 and Y.shape[1] % 8 == 0 and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0
+            and out.shape == (X.shape[1], Y.shape[1]))
+
+
+def gemm_tn_f32(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor, *, colsum_out: torch.Tensor | None = None, f32_split: int = 0):
+    """out[P, Q] += X[M, P]^T @ Y[M, Q] (fp32 operands as stored: the weight gradient dy^T x without transposed copies; split-bf16
+    products, f32_split 2 / 3 / 0 = default); `colsum_out` fp32 [P] += column sums of X (the bias gradient)"""
+    assert gemm_tn_f32_supported(X, Y, out)
+    M, P = X.shape
+    Q = Y.shape[1]
+    if colsum_out is not None:
+        assert colsum_out.dtype == torch.float32 and colsum_out.is_contiguous() and colsum_out.numel() == P
+    hip.call('vm_gemm_tn_f32', ptr(X), _ld(X), P, ptr(Y), _ld(Y), Q, ptr(out), _ld(out), M, ptr(colsum_out), f32_split, stream())
+    return out
+
+
 @functools.lru_cache(maxsize=256)
 def _tn_skinny_ws_bytes(M: int, Cw: int) -> int:
     n = C.c_int64(0)

@@ -718,6 +718,30 @@ def test_lora_down_fused_producers(dev, K, M, Kd):
     assert rel_err(K.lora_down_fused(K.LD_GELU, h, None, A)[1], tt) < 6e-3
 
 
+@pytest.mark.parametrize('M,P,Q', [(3136, 768, 3072), (3136, 3072, 768), (777, 768, 768), (100, 64, 136), (2049, 2304, 768)])
+@pytest.mark.parametrize('split', [2, 3])
+def test_gemm_tn_f32(dev, K, M, P, Q, split):
+    """fp32 weight gradient in TN form (vm_gemm_tn_f32): C += X^T Y on the operands as stored, bias gradient (column sums of X) on the
+    side, against fp64; the three-product mode carries 16 mantissa bits per product, the six-product mode fp32 products"""
+    g = torch.Generator(device=dev).manual_seed(M + P)
+    X = torch.randn(M, P, device=dev, generator=g)
+    Y = torch.randn(M, Q, device=dev, generator=g)
+    base = torch.randn(P, Q, device=dev, generator=g)
+    out = base.clone()
+    cs = torch.ones(P, device=dev)
+    K.gemm_tn_f32(X, Y, out, colsum_out=cs, f32_split=split)
+    ref = base.double() + X.double().T @ Y.double()
+    err = ((out.double() - ref).norm() / ref.norm()).item()
+    assert err < (2e-5 if split == 2 else 2e-6), err
+    assert rel_err(cs, 1 + X.sum(0)) < 1e-5
+    # strided operands (column slices of wider buffers), second accumulation on top
+    Xw = torch.randn(M, P + 8, device=dev, generator=g)
+    out2 = out.clone()
+    K.gemm_tn_f32(Xw[:, 8:], Y, out2, f32_split=split)
+    ref2 = out.double() + Xw[:, 8:].double().T @ Y.double()
+    assert ((out2.double() - ref2).norm() / ref2.norm()).item() < (2e-5 if split == 2 else 2e-6)
+
+
 def test_tn_skinny_group(dev, K):
     """a batch of LoRA factor gradients in one launch (vm_tn_skinny_group_bf16): every item against a torch fp32 contraction — both
     output orientations, bf16 and fp32 slots, accumulation into non-zero slots, routed row segments from device counts (an empty

@@ -12,4 +12,6 @@ TRACE=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
 STATS=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1)
 python3 tools/step_timeline.py $TRACE gpurun_out/${TAG}_timeline.md > /dev/null
 python3 tools/summarize_prof.py $STATS gpurun_out/${TAG}_kernel_stats.md "$TAG: bench.py --steps 4 --warmup 2 $* (planning + calibration steps included)" > /dev/null
+python3 tools/trace_by_grid.py $TRACE gpurun_out/${TAG}_by_grid.md > /dev/null
+head -1 $TRACE > gpurun_out/${TAG}_trace_header.csv
 head -40 gpurun_out/${TAG}_timeline.md
