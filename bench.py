@@ -390,6 +390,8 @@ def main():
                     help='also bracket attention / fp32 GEMM / LoRA launches (default: only the dominant bf16 GEMM)')
     ap.add_argument('--event-stride', type=int, default=4, help='bracket a pseudo-random 1-in-n sample of the launches of the dominant kernel with HIP events')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
+    ap.add_argument('--no-calibrate', action='store_true',
+                    help='counter-collection runs only (tools/pmc_step.sh): keep the planning step but skip the calibration steps that follow it')
     ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed'),
                     help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
                          "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
@@ -487,7 +489,7 @@ def main():
         # every step (3D workloads: 850 -> 1570 ms/step, thousands of hipMalloc / hipFree per step), so the budget is cut by
         # the overshoot and the step repeated.
         target = int(args.hbm_fraction * total_hbm)
-        for _ in range(5):
+        for _ in range(0 if args.no_calibrate else 5):
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats()
             try:
@@ -537,18 +539,16 @@ def main():
     if use_events:
         K.prof_reset()
         K.prof_stride(args.event_stride)
-        K.prof_enable(True if args.all_kernel_events else (hip.PROF_GEMM_BF16,))
+        # the dominant GEMM (1-in-stride sample) and the ~350 attention launches of a step; --all-kernel-events adds fp32 GEMM / LoRA
+        K.prof_enable(True if args.all_kernel_events else (hip.PROF_GEMM_BF16, hip.PROF_ATTN))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     model.freeze_python_gc()          # model, buckets, optimizer state and the batch are permanent: keep the cyclic GC off them
     ms0 = torch.cuda.memory_stats(device)
-    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        h0 = time.perf_counter()
         loss = step()
-        host_s += time.perf_counter() - h0          # until every launch of the step is enqueued (the host never waits inside a step)
     torch.cuda.synchronize()
     ms1 = torch.cuda.memory_stats(device)
     if use_dist:
@@ -561,6 +561,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss_v = float(loss.item())
+    # host enqueue time of a step: inside the timed region the host runs ahead of the GPU until the launch queue throttles it, so its
+    # per-step wall time there equals the GPU's. Two more steps (untimed), each started from an idle GPU: time until step() returns.
+    host_enq = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        step()
+        host_enq.append((time.perf_counter() - h0) * 1e3)
+    torch.cuda.synchronize()
     if world > 1:
         ddp.assert_replicas_equal(what='trainable parameters after the timed region')       # identical updates of averaged gradients
 
@@ -576,7 +585,8 @@ def main():
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
                        'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
-            'host_enqueue_ms': host_s / args.steps * 1e3,
+            'host_enqueue_ms': min(host_enq),
+            'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min of 2 untimed steps after the timed region); must stay below ms_per_step',
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
             # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
             'allocator': {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
@@ -608,7 +618,10 @@ def main():
                                'note': 'algorithmic 2*M*N*(K+K2) FLOPs summed over the bracketed launches of the timed region / their summed HIP-event durations'}
             ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)
             if n_a:
-                out['attention'] = {'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12, 'launches': n_a, 'kernel_time_share': ms_a * 1e-3 / dt}
+                stride_a = args.event_stride if not args.all_kernel_events else args.event_stride
+                out['attention'] = {'kernel': 'attn16_fwd_k / attn16_dq_k / attn16_dkv_k (vm_attn_*_bf16)', 'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12,
+                                    'frac_of_bf16_peak': fl_a / (ms_a * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 'launches': n_a,
+                                    'kernel_time_share': ms_a * stride_a * 1e-3 / dt}
             ms_f, fl_f, n_f = K.prof_collect(hip.PROF_GEMM_F32)
             if n_f:
                 out['gemm_f32'] = {'achieved_tflops': fl_f / (ms_f * 1e-3) / 1e12, 'launches': n_f, 'kernel_time_share': ms_f * 1e-3 / dt}

@@ -75,6 +75,9 @@ class BucketedGradAllReduce:
             p._vm_grad_ready = self._note_stream
             if p.dtype == torch.bfloat16 and p.is_cuda:
                 p._vm_f32_acc = self.f32_accumulator
+        from . import functional as Fh
+        for p in self.params:          # checkpointed backward nodes see detached aliases of their parameters: find the real ones by address
+            Fh.PARAM_BY_PTR[p.data_ptr()] = p
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):
@@ -328,6 +331,10 @@ class BucketedGradAllReduce:
         return total
 
     def remove(self):
+        from . import functional as Fh
+        for p in self.params:
+            if Fh.PARAM_BY_PTR.get(p.data_ptr()) is p:
+                del Fh.PARAM_BY_PTR[p.data_ptr()]
         for p in self.params:
             if getattr(p, '_vm_grad_ready', None) is not None:
                 del p._vm_grad_ready

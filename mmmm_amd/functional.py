@@ -255,6 +255,22 @@ def flush_wgrad_queue():
             torch.cuda.set_stream(cur)
 
 
+# Parameters whose gradients live in flat reduction buckets, by storage address (filled by ddp.BucketedGradAllReduce). Under activation
+# checkpointing (torch.utils.checkpoint, non-reentrant) a backward node gets its saved tensors back as DETACHED aliases of what the
+# recomputed forward saved: a saved parameter then is a plain tensor without `.grad` and without the bucket's tags, and the kernels
+# would fall back to returning gradient tensors for AccumulateGrad — every layer of the reference's own checkpoint-everything mode
+# took that path (found when the grouped launch made the two paths differ in the last bit: tools/debug_group_inputs.py).
+PARAM_BY_PTR: dict = {}
+
+
+def _real_param(p):
+    """the registered Parameter behind a (possibly detached) alias of it, else `p` itself"""
+    if p is None or getattr(p, '_vm_grad_ready', None) is not None:
+        return p
+    q = PARAM_BY_PTR.get(p.data_ptr())
+    return q if (q is not None and q.shape == p.shape and q.dtype == p.dtype) else p
+
+
 def _direct_slot(param):
     """the parameter's gradient lives in a flat reduction bucket the kernels may accumulate into (ddp.BucketedGradAllReduce)"""
     return (getattr(param, '_vm_grad_ready', None) is not None and param.grad is not None
@@ -269,6 +285,7 @@ def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
         if transpose_out:
             return K.gemm_tn(S, W, counts=counts, segment=seg, alpha=scale, drop_p=drop_p, drop_seed=seed)
         return K.gemm_tn(W, S, counts=counts, segment=seg, alpha=scale)
+    param = _real_param(param)
     if _direct_slot(param):
         ready = param._vm_grad_ready
         if WGRAD_GROUP:
@@ -288,7 +305,7 @@ def _lora_wgrad(param, W, S, transpose_out, counts, seg, scale, drop_p, seed):
 def _lora_wgrad_pair(params, W, S, transpose_out, counts, scale, drop_p, seed):
     """both experts of a gated linear in ONE launch (segment 0 -> params[0], segment 1 -> params[1]); returns the pair of
     gradients for autograd (None where the kernel accumulated straight into the bucket view)."""
-    p0, p1 = params
+    p0, p1 = (_real_param(q) for q in params)
     direct = _direct_slot(p0) and _direct_slot(p1) and p0.grad.dtype == p1.grad.dtype and p0.grad.stride() == p1.grad.stride()
     if direct and WGRAD_GROUP:
         _queue_wgrad(p0, p0._vm_grad_ready, W, S, transpose_out, counts, 0, scale, drop_p, seed)
@@ -434,6 +451,7 @@ class _Linear(Function):
                 # full fp32 weight gradient of an ungated, LoRA-free linear whose gradient lives in a reduction bucket (the
                 # unfrozen SAM / iSAM / vg_proj linears): W.grad += dy^T x through the GEMM's residual path, transposes
                 # included, on the side stream — off the critical path, no temporary, no AccumulateGrad add
+                W, b = _real_param(W), _real_param(b)
                 wready = getattr(W, '_vm_grad_ready', None)
                 bias_done = False
                 if (need[base] and not gated and not lora and wready is not None and W.grad is not None and W.grad.dtype == torch.float32
@@ -495,7 +513,7 @@ def _norm_params_off_path(params, run_kernel, keep_alive):
     """Weight / bias gradients of a norm layer, when their slots live in a gradient bucket: computed on the side stream and
     added straight into the slots (fp32 slots: the kernel's atomics land there; bf16 slots: fp32 scratch, rounded, added —
     the same rounding as AccumulateGrad would apply). Returns True when it took care of them."""
-    ps = [p for p in params if p is not None]
+    ps = [_real_param(p) for p in params if p is not None]
     if not ps or any(getattr(p, '_vm_grad_ready', None) is None or p.grad is None or not p.grad.is_contiguous() for p in ps):
         return False
 

@@ -229,6 +229,34 @@ def test_config0_true_width_reduced_depth_end_to_end_vs_oracle(dev, cfg0, instan
     for n in WATCH + WATCH_HEAD[instance]:
         assert ps[n].grad is not None, n
         _bounds(f'{tag} grad {n}', ps[n].grad.float().cpu(), r16['grads'][n], r32['grads'][n], a=1.5, b=1.8, floor=2e-4)
+    # ... and their PARAMETER gradients on identical prompts, true width (the image encoder's blocks run the three-product
+    # split-bf16 arithmetic, image_encoder.ENCODER_F32_SPLIT = 2: this is the measurement behind that default)
+    head, pre = (m.isam_model, 'isam_model') if instance else (m.sam, 'sam')
+    names = [n[len(pre) + 1:] for n in WATCH_HEAD[instance]] + ['image_encoder.blocks.5.mlp.linear1.weight', 'image_encoder.blocks.5.attn.out_proj.weight',
+                                                               'image_encoder.norm.weight', 'image_encoder.patch_embedding.proj.weight']
+    hp = dict(head.named_parameters())
+    names = [n for n in names if n in hp]
+    for n in names:
+        hp[n].grad = None
+    hsd = {f'{pre}.{k}': v.detach().float().cpu() for k, v in head.state_dict().items()}
+    for n in names:
+        hsd[f'{pre}.{n}'].requires_grad_(True)
+    pin = [r32['cap']['prompts'][0].detach().to(dev)]
+    pin_c = [r32['cap']['prompts'][0].detach().clone()]
+    gim = [x.cpu() for x in batch['grounding_image']]
+    if instance:
+        o = head(batch['grounding_image'], batch['patch_size'], pin)
+        (o.boxes[0].sum() + o.disc_logit[0].square().sum()).backward()
+        _, _, bx, dl = O.isam_forward(hsd, scfg.isam, pre, gim, batch['patch_size'], pin_c)
+        (bx[0].sum() + dl[0].square().sum()).backward()
+    else:
+        head(batch['grounding_image'], batch['patch_size'], pin)[0].square().mean().backward()
+        O.sam_forward(hsd, scfg.sam, pre, gim, batch['patch_size'], pin_c)[0].square().mean().backward()
+    ge = {n: rel(hp[n].grad, hsd[f'{pre}.{n}'].grad) for n in names}
+    REPORT[f'{tag} fp32 island parameter gradients on identical prompts (true width)'] = ge
+    assert len(ge) >= 5 and all(v < 1e-4 for v in ge.values()), ge
+    for n in names:
+        hp[n].grad = None
 
 
 def test_depth_sweep_true_width_decoder(dev):
