@@ -139,10 +139,13 @@ __device__ __forceinline__ bf16x8_t pack2(const f32x4_t& a, const f32x4_t& b) {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // x <= 0 here; denormal results flush to 0
 
 // physical rows of the two 4-row groups this lane stages for the 64-position tile starting at pos0
+// NW = waves per workgroup (8: 128 positions per block, 16: 256): a 64-row tile is 16 wave-instructions of 4 rows, 16 / NW per wave
+template <int NW>
 __device__ __forceinline__ void a16_rows(const AttnP& p, int seq0, int seqlen, int pos0, int wave, int lane, int (&pr)[2]) {
+  constexpr int PW = 16 / NW;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pos = pos0 + (wave * 2 + i) * 4 + (lane >> 4);
+  for (int i = 0; i < PW; ++i) {
+    const int pos = pos0 + (wave * PW + i) * 4 + (lane >> 4);
     pr[i] = pos < seqlen ? phys_row(p, seq0 + pos) : 0;
   }
 }
@@ -151,23 +154,26 @@ __device__ __forceinline__ void a16_rows(const AttnP& p, int seq0, int seqlen, i
 struct StageLane {
   int row[2];    // tile row of wave-instruction i
   int col[2];    // byte offset of the lane's source chunk inside a row of the operand, or -1 past the head dimension
-  template <int HD>
+  template <int HD, int NW>
   __device__ __forceinline__ void init(int head, int wave, int lane) {
+    constexpr int PW = 16 / NW;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      row[i] = (wave * 2 + i) * 4 + (lane >> 4);
+    for (int i = 0; i < PW; ++i) {
+      row[i] = (wave * PW + i) * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ swz16(row[i]);
       col[i] = chunk * 8 < HD ? (head * HD + chunk * 8) * 2 : -1;
     }
   }
 };
+template <int NW>
 __device__ __forceinline__ void a16_stage(__amdgpu_buffer_rsrc_t rs, int ld_b, const StageLane& sl, int rows_left, const int (&pr)[2],
                                           char* tile, int wave) {
+  constexpr int PW = 16 / NW;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < PW; ++i) {
     const bool valid = sl.row[i] < rows_left && sl.col[i] >= 0;
     const int voff = valid ? (int)__umul24(pr[i], ld_b) + sl.col[i] : OOB_OFF;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(tile + (wave * 2 + i) * 1024), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(tile + (wave * PW + i) * 1024), 16, voff, 0, 0, 0);
   }
 }
 
@@ -189,8 +195,19 @@ __device__ __forceinline__ bool a16_block(const AttnP& p, int& tile, int& head, 
 }
 
 // ----------------------------------------------------------------------------- forward (16 queries per wave)
-template <int HD>
-__global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
+// STG (stagger): the second half of the workgroup's waves (one of every two waves that share a SIMD: guide 'Two waves per SIMD',
+// item 9: split by wave number, not parity) defers the P V product of a tile to the NEXT iteration. Every wave runs
+// S = K Q^T (MFMA) -> softmax (VALU) -> O += V^T P^T (MFMA) and the one barrier per tile keeps all waves in step, so without the
+// stagger the SIMD's waves fight for the matrix pipe in two of the three phases and for the VALU in the third (PMC, round 3:
+// MFMA busy 0.24, parked at s_waitcnt / barrier 0.43 of the wave cycles). With it the late half runs [P V of tile t-1, S of t, softmax]
+// against the early half's [S, softmax, P V]: the early half's softmax meets the late half's S product, the early half's P V the late
+// half's softmax. V tiles then live one iteration longer: K ring of 2, V ring of 3 (80 KiB, two 8-wave workgroups per CU).
+constexpr int A16_TILE = 64 * ROWB;
+constexpr int A16_LDS_FWD = 5 * A16_TILE;           // K[2] | V[3]
+
+template <int HD, int NW, bool STG>
+__global__ __launch_bounds__(NW * 64, 4) void attn16_fwd_k(const AttnP p) {
+  constexpr int QB = NW * 16;            // positions per workgroup
   constexpr int KS = (HD + 31) / 32;
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,11 +218,12 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
   if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = tile_ * 128;
+  const int q0 = tile_ * QB;
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
   const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
+  const bool late = STG && wave >= NW / 2;
 
   bf16x8_t qf[KS];
 #pragma unroll
@@ -220,30 +238,41 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = p.scale * LOG2E;
 
-  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
+  const int kv_end = p.causal ? min(seqlen, q0 + QB) : seqlen;
   const int nt = (kv_end + 63) / 64;
   const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
   const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
+  char* kring = smem;                       // tile t in slot t & 1
+  char* vring = smem + 2 * A16_TILE;        // tile t in slot t % 3
   StageLane sl;
-  sl.init<HD>(head, wave, lane);
+  sl.init<HD, NW>(head, wave, lane);
   int pr[2];
-  a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
-  a16_stage(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
-  a16_stage(rV, ldv_b, sl, seqlen - (0), pr, smem + 64 * ROWB, wave);
-  if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
+  a16_rows<NW>(p, seq0, seqlen, 0, wave, lane, pr);
+  a16_stage<NW>(rK, ldk_b, sl, seqlen - (0), pr, kring, wave);
+  a16_stage<NW>(rV, ldv_b, sl, seqlen - (0), pr, vring, wave);
+  if (nt > 1) a16_rows<NW>(p, seq0, seqlen, 64, wave, lane, pr);
   A16_WAIT_ALL();
   __syncthreads();
 
+  bf16x8_t pprev[2];                        // late waves: P of the previous tile, waiting for its P V
+  auto pv = [&](const char* sV, const bf16x8_t (&pf)[2]) {      // O^T[d][q] += V^T · P^T
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int b = 0; b < ND; ++b)
+        o[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sV, 32 * c, b, lane), pf[c], o[b], 0, 0, 0);
+  };
+  int vs = 0;                               // V ring slot of tile t (t % 3 without a division)
   for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
+    const int vs_next = vs == 2 ? 0 : vs + 1;
     if (t + 1 < nt) {
-      char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
-      a16_stage(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, nb + 64 * ROWB, wave);
-      if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
+      a16_stage<NW>(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, kring + ((t + 1) & 1) * A16_TILE, wave);
+      a16_stage<NW>(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, vring + vs_next * A16_TILE, wave);
+      if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
     }
-    const char* sK = smem + buf * A16_STAGE;
-    const char* sV = sK + 64 * ROWB;
+    const char* sK = kring + (t & 1) * A16_TILE;
+    const char* sV = vring + vs * A16_TILE;
+    if (late && t > 0) pv(vring + (vs == 0 ? 2 : vs - 1) * A16_TILE, pprev);      // the deferred product of tile t - 1
     const int kv0 = t * 64;
     // S^T sub-tiles: sacc[j][r] = score(kv = kv0 + 16 j + 4 g + r, q = this lane's query)
     f32x4_t sacc[4];
@@ -287,17 +316,14 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
     m_run = m_new;
 #pragma unroll
     for (int b = 0; b < ND; ++b) o[b] *= alpha;            // (a wave-uniform "max unchanged" branch costs more in copies)
-    // O^T[d][q] += V^T · P^T
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const bf16x8_t pf = pack2(sacc[2 * c], sacc[2 * c + 1]);
-#pragma unroll
-      for (int b = 0; b < ND; ++b)
-        o[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sV, 32 * c, b, lane), pf, o[b], 0, 0, 0);
-    }
+    const bf16x8_t pf[2] = {pack2(sacc[0], sacc[1]), pack2(sacc[2], sacc[3])};
+    if (late) { pprev[0] = pf[0]; pprev[1] = pf[1]; }
+    else pv(sV, pf);
+    vs = vs_next;
     A16_WAIT_ALL();
     __syncthreads();
   }
+  if (late && nt > 0) pv(vring + (vs == 0 ? 2 : vs - 1) * A16_TILE, pprev);        // (no DMA is in flight any more: the last V tile is intact)
 
   if (!qvalid) return;
   const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -311,8 +337,9 @@ __global__ __launch_bounds__(512, 4) void attn16_fwd_k(const AttnP p) {
 }
 
 // ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
-template <int HD>
-__global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
+  constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
   if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = tile_ * 128;
+  const int q0 = tile_ * QB;
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
@@ -348,17 +375,17 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
 #pragma unroll
   for (int b = 0; b < ND; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int kv_end = p.causal ? min(seqlen, q0 + 128) : seqlen;
+  const int kv_end = p.causal ? min(seqlen, q0 + QB) : seqlen;
   const int nt = (kv_end + 63) / 64;
   const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
   const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
   StageLane sl;
-  sl.init<HD>(head, wave, lane);
+  sl.init<HD, NW>(head, wave, lane);
   int pr[2];
-  a16_rows(p, seq0, seqlen, 0, wave, lane, pr);
-  a16_stage(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
-  a16_stage(rV, ldv_b, sl, seqlen - (0), pr, smem + 64 * ROWB, wave);
-  if (nt > 1) a16_rows(p, seq0, seqlen, 64, wave, lane, pr);
+  a16_rows<NW>(p, seq0, seqlen, 0, wave, lane, pr);
+  a16_stage<NW>(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
+  a16_stage<NW>(rV, ldv_b, sl, seqlen - (0), pr, smem + 64 * ROWB, wave);
+  if (nt > 1) a16_rows<NW>(p, seq0, seqlen, 64, wave, lane, pr);
   A16_WAIT_ALL();
   __syncthreads();
 
@@ -366,9 +393,9 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
     const int buf = t & 1;
     if (t + 1 < nt) {
       char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
-      a16_stage(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, nb + 64 * ROWB, wave);
-      if (t + 2 < nt) a16_rows(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
+      a16_stage<NW>(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
+      a16_stage<NW>(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, nb + 64 * ROWB, wave);
+      if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
     }
     const char* sK = smem + buf * A16_STAGE;
     const char* sV = sK + 64 * ROWB;
@@ -415,8 +442,9 @@ __global__ __launch_bounds__(512, 4) void attn16_dq_k(const AttnP p) {
 }
 
 // ----------------------------------------------------------------------------- backward: dK, dV (16 keys per wave)
-template <int HD>
-__global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 1) void attn16_dkv_k(const AttnP p) {
+  constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
   constexpr int ND = HD / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
   if (!a16_block(p, tile_, head, seq)) return;
   const int seq0 = p.cu[seq];
   const int seqlen = p.cu[seq + 1] - seq0;
-  const int k0 = tile_ * 128;
+  const int k0 = tile_ * QB;
   if (k0 >= seqlen) return;
   const int kpos = k0 + wave * 16 + ln;
   const bool kvalid = kpos < seqlen;
@@ -464,13 +492,13 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
     }
   };
   StageLane sl;
-  sl.init<HD>(head, wave, lane);
+  sl.init<HD, NW>(head, wave, lane);
   int pr[2];
-  a16_rows(p, seq0, seqlen, q_begin, wave, lane, pr);
-  a16_stage(rQ, ldq_b, sl, seqlen - (q_begin), pr, smem, wave);
-  a16_stage(rDO, lddo_b, sl, seqlen - (q_begin), pr, smem + 64 * ROWB, wave);
+  a16_rows<NW>(p, seq0, seqlen, q_begin, wave, lane, pr);
+  a16_stage<NW>(rQ, ldq_b, sl, seqlen - (q_begin), pr, smem, wave);
+  a16_stage<NW>(rDO, lddo_b, sl, seqlen - (q_begin), pr, smem + 64 * ROWB, wave);
   stage_stats(q_begin, 0);
-  if (nt > 1) a16_rows(p, seq0, seqlen, q_begin + 64, wave, lane, pr);
+  if (nt > 1) a16_rows<NW>(p, seq0, seqlen, q_begin + 64, wave, lane, pr);
   A16_WAIT_ALL();
   __syncthreads();
 
@@ -479,16 +507,16 @@ __global__ __launch_bounds__(512) void attn16_dkv_k(const AttnP p) {
     const int qq0 = q_begin + t * 64;
     if (t + 1 < nt) {
       char* nb = smem + (buf ^ 1) * A16_STAGE;
-      a16_stage(rQ, ldq_b, sl, seqlen - (qq0 + 64), pr, nb, wave);
-      a16_stage(rDO, lddo_b, sl, seqlen - (qq0 + 64), pr, nb + 64 * ROWB, wave);
+      a16_stage<NW>(rQ, ldq_b, sl, seqlen - (qq0 + 64), pr, nb, wave);
+      a16_stage<NW>(rDO, lddo_b, sl, seqlen - (qq0 + 64), pr, nb + 64 * ROWB, wave);
       stage_stats(qq0 + 64, buf ^ 1);
-      if (t + 2 < nt) a16_rows(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
+      if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
     }
     const char* sQ = smem + buf * A16_STAGE;
     const char* sDO = sQ + 64 * ROWB;
     const float* sL = stats + buf * 128;
     const float* sD = sL + 64;
-    const bool edge = qq0 + 64 > seqlen || (p.causal && qq0 < k0 + 128);
+    const bool edge = qq0 + 64 > seqlen || (p.causal && qq0 < k0 + QB);
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
       // S[q][key], dP[q][key] for 32 queries: lane (key = ln, g) holds q = qq0 + 32 hq + 16 jj + 4 g + r
@@ -549,7 +577,7 @@ AttnP to_params(const vm_attn_args* a) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
   p.lse = a->lse; p.cu = a->cu_seqlens; p.row_of_pos = a->row_of_pos;
   p.total_pos_max = a->total_pos_max; p.n_heads = a->n_heads;
-  p.n_seq = a->n_seq; p.n_tiles = (a->max_seqlen + 127) / 128;
+  p.n_seq = a->n_seq; p.n_tiles = (a->max_seqlen + 127) / 128;      // (the launchers overwrite n_tiles with their block size)
   p.scale = a->scale; p.causal = a->causal;
   p.dout = (const unsigned short*)a->dout; p.lddo = a->lddo;
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv;
@@ -576,9 +604,25 @@ bool fits32(const vm_attn_args* a) {
          (!a->dout || rows * a->lddo * 2 < OOB_OFF) && (int64_t)a->n_heads * a->total_pos_max * 4 < OOB_OFF;
 }
 
-dim3 grid16(const vm_attn_args* a) {
+dim3 grid16(const vm_attn_args* a, int qb) {
   const int pairs8 = (a->n_heads * a->n_seq + 7) / 8 * 8;
-  return dim3((unsigned)(pairs8 * ((a->max_seqlen + 127) / 128)));
+  return dim3((unsigned)(pairs8 * ((a->max_seqlen + qb - 1) / qb)));
+}
+// waves per workgroup: 16 (256 positions per block: every K/V (Q/dO) tile a workgroup streams serves twice the positions — these
+// kernels are bound by the bytes their CUs take in through LDS-DMA, 373 MB per ViT-E forward launch with 128-position blocks) unless
+// the sequences are short; VM_ATTN_NW=8 restores round 2's 128-position blocks
+// Measured [r3]: 16 waves are NOT faster (ViT-E forward 83 vs 79 us, the step 314.3 vs 314.0 ms): what bounds these kernels is not the
+// operand stream but the phases of a wave not overlapping (see the stagger above). Default 8; VM_ATTN_NW=16 for A/B runs.
+int attn_nw(const vm_attn_args* a) {
+  static const int forced = [] { const char* e = getenv("VM_ATTN_NW"); return e ? atoi(e) : 8; }();
+  return (forced == 16 && a->max_seqlen > 192) ? 16 : 8;
+}
+// Measured [r3]: the staggered forward is SLOWER — ViT-E [8 x 785, 16 heads of 112] 107 vs 82 us, decoder [8 x 456, 32 heads of 128,
+// causal] 85 vs 51 us (tools/bench_attn.py, one process each): the two orders of the loop body cost 12-28 VGPR spill slots under the
+// 128-register cap that four waves per SIMD impose. Off by default; VM_ATTN_STAGGER=1 for A/B runs.
+bool attn_stagger() {
+  static const int v = [] { const char* e = getenv("VM_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
+  return v != 0;
 }
 
 double attn_flops(const vm_attn_args* a, double mult) {
@@ -610,9 +654,14 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
+  const int nw = attn_nw(a);
+  p.n_tiles = (a->max_seqlen + nw * 16 - 1) / (nw * 16);
     ATTN_DISPATCH_HD(a->head_dim,
-                     if (!lds_ok((const void*)attn16_fwd_k<HD>, A16_LDS)) return VM_ERR_LAUNCH;
-                     hipLaunchKernelGGL(attn16_fwd_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p));
+                     if (!lds_ok((const void*)attn16_fwd_k<HD, 8, true>, A16_LDS_FWD) || !lds_ok((const void*)attn16_fwd_k<HD, 16, true>, A16_LDS_FWD) ||
+                         !lds_ok((const void*)attn16_fwd_k<HD, 8, false>, A16_LDS_FWD)) return VM_ERR_LAUNCH;
+                     if (nw == 16) hipLaunchKernelGGL((attn16_fwd_k<HD, 16, true>), grid16(a, 256), dim3(1024), A16_LDS_FWD, (hipStream_t)stream, p);
+                     else if (attn_stagger()) hipLaunchKernelGGL((attn16_fwd_k<HD, 8, true>), grid16(a, 128), dim3(512), A16_LDS_FWD, (hipStream_t)stream, p);
+                     else hipLaunchKernelGGL((attn16_fwd_k<HD, 8, false>), grid16(a, 128), dim3(512), A16_LDS_FWD, (hipStream_t)stream, p));
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
   VM_LAUNCH_CHECK();
   return VM_OK;
@@ -627,12 +676,22 @@ int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
+  const int nw = attn_nw(a);
+  static const int dkv_forced = [] { const char* e = getenv("VM_ATTN_DKV_NW"); return e ? atoi(e) : 8; }();
+  const int dkv_nw = (dkv_forced == 16 && nw == 16) ? 16 : 8;
+  p.n_tiles = (a->max_seqlen + nw * 16 - 1) / (nw * 16);
     ATTN_DISPATCH_HD(a->head_dim,
-                     if (!lds_ok((const void*)attn16_dq_k<HD>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
+                     if (!lds_ok((const void*)attn16_dq_k<HD, 8>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 8>, A16_LDS_DKV) ||
+                         !lds_ok((const void*)attn16_dq_k<HD, 16>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 16>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
                      hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
                                         (hipStream_t)stream, p, a->n_seq);
-                     hipLaunchKernelGGL(attn16_dq_k<HD>, grid16(a), dim3(512), A16_LDS, (hipStream_t)stream, p);
-                     hipLaunchKernelGGL(attn16_dkv_k<HD>, grid16(a), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
+                     if (nw == 16) hipLaunchKernelGGL((attn16_dq_k<HD, 16>), grid16(a, 256), dim3(1024), A16_LDS, (hipStream_t)stream, p);
+                     else hipLaunchKernelGGL((attn16_dq_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS, (hipStream_t)stream, p);
+                     // dK / dV: 164 VGPRs per wave (two accumulator sets): 16 waves per workgroup would spill (26-49 slots), so its blocks stay
+                     // at 128 keys unless VM_ATTN_DKV_NW=16 asks for the spilling form (A/B measurements)
+                     p.n_tiles = (a->max_seqlen + dkv_nw * 16 - 1) / (dkv_nw * 16);
+                     if (dkv_nw == 16) hipLaunchKernelGGL((attn16_dkv_k<HD, 16>), grid16(a, 256), dim3(1024), A16_LDS_DKV, (hipStream_t)stream, p);
+                     else hipLaunchKernelGGL((attn16_dkv_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
   VM_LAUNCH_CHECK();
   return VM_OK;
