@@ -583,7 +583,7 @@ def main():
             'vs_baseline': None, 'dtype': 'fp8-e4m3 frozen-weight GEMMs (fwd + dgrad), bf16 elsewhere' if args.fp8 else 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (VM_ENC_F32_SPLIT=%s)' % os.environ.get('VM_ENC_F32_SPLIT', '2')) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             'host_enqueue_ms': min(host_enq),
             'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min of 2 untimed steps after the timed region); must stay below ms_per_step',

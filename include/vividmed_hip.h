@@ -44,7 +44,8 @@ extern "C" {
 #define VM_ACT_RELU 2
 
 /* library / device info --------------------------------------------------- */
-int vm_version(void);
+int vm_version(void);   /* 300 = round 3. The argument structs below only ever GROW at their end; a caller built against an older
+                          * header must be rebuilt when this number changes (there is no struct_size field). */
 /* fills name[0..len) with the gcnArchName of the current device */
 int vm_device_arch(char* name_host, int len);
 
@@ -192,9 +193,14 @@ int vm_scale_rows_bf16(const void* x, int64_t ldx, const float* s, void* out, in
  *   0  v_mfma_f32_16x16x4_f32, the exact f32 fma chain (1/16 of the bf16 matrix rate);
  *   2  split-bf16: a = a0 + a1, b = b0 + b1 with bf16 terms split in registers, a.b ~ a0 b0 + a0 b1 + a1 b0 on
  *      v_mfma_f32_16x16x32_bf16 with fp32 accumulation — products carry 16 mantissa bits. Measured (tools/bench_gemm_f32.py,
- *      tools/f32_mode_accuracy.py): 1.6-2.3x faster than mode 0 on the heads' shapes, 3e-6 relative error per product matrix,
- *      1.2e-5 end to end on SAM-B's masks (mode 0: 1.3e-6) but up to 9e-4 on the prompt gradients through iSAM — outside the 1e-4
- *      bar of the fp32 islands, hence opt-in;
+ *      tools/f32_mode_accuracy.py): 1.6-2.3x faster than mode 0 on the heads' shapes, 3e-6 relative error per product matrix.
+ *      As the PROCESS-WIDE mode (every linear of the islands, the mask decoder's included) it gives 1.2e-5 end to end on SAM-B's
+ *      masks and up to 9e-4 on the prompt gradients through iSAM — outside the 1e-4 bar of the fp32 islands, so it is not the
+ *      process default. PER LAYER (vm_gemm_args.f32_split = 2) the product uses it for the 12 blocks of the two SAM-B image
+ *      encoders only (models/segvol/modeling/image_encoder.py); the mask decoder, through which the prompt gradients flow, keeps
+ *      mode 3. Measured in that configuration at TRUE width against the fp32 oracle (tests/test_config0_gpu.py,
+ *      profiles/r3_parity_report.json): masks 1.3e-6, boxes 2.8e-7, discriminator 7.3e-7, encoder parameter gradients
+ *      8e-7 .. 3.3e-6, mask-decoder / box-head parameter gradients 5e-7 .. 1.2e-6 — all two orders inside the 1e-4 bar;
  *   3  (default) three terms, six products: 24 mantissa bits, i.e. fp32 products — error as mode 0 (4e-7 per product matrix,
  *      1.3e-6 end to end), 1.2-1.4x faster than mode 0. */
 int vm_gemm_f32(const vm_gemm_args* args_host, void* stream);
@@ -283,7 +289,11 @@ int vm_embedding_bwd(const void* dout, int64_t ld, const int32_t* sorted_ids, co
 
 /* out[c, r] = in[r, c]; columns >= rows_true (device count, optional) are zero-filled
  * up to `rows` — and on to min(ld_out, rows rounded up to 64): the pad columns of a K-padded output row need no separate
- * fill — so that the result can be the K-contiguous operand of an NT GEMM (weight-gradient GEMMs contract over tokens). */
+ * fill — so that the result can be the K-contiguous operand of an NT GEMM (weight-gradient GEMMs contract over tokens).
+ * NOTE for callers that transpose INTO A COLUMN SLICE of a wider matrix (ld_out > rows with live data to the right of the slice):
+ * columns [rows, min(ld_out, roundup64(rows))) of every output row are OVERWRITTEN with zeros (vm_transpose, vm_transpose_segment and
+ * vm_transpose_colsum alike; since round 2). Give such an output a row pitch of exactly `rows`' slice only if rows % 64 == 0, or
+ * transpose into a buffer of its own. */
 int vm_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out,
                  int rows, int cols, int dtype, const int32_t* nrows_dev, void* stream);
 

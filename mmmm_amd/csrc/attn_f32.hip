@@ -647,9 +647,9 @@ int vm_attn_fwd_f32(const vm_attn_f32_args* a, void* stream) {
   AP p = to_ap(a);
   dim3 grid((a->Lq + 127) / 128, a->n_heads, p.Bn);
   void* tok = nullptr;
-  vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
   // f32_split (head_dim 64, the SAM ViT-B encoders): the products on split-bf16 MFMAs instead of the exact f32 MFMA chain
-  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
+  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;          // (argument checks come before the profiling bracket opens)
+  vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
   if (a->f32_split >= 2 && a->head_dim == 64) {
     if (a->f32_split == 2) hipLaunchKernelGGL((attn_f32_fwd_k<64, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_f32_fwd_k<64, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -668,8 +668,8 @@ int vm_attn_bwd_f32(const vm_attn_f32_args* a, void* stream) {
   dim3 gq((a->Lq + 127) / 128, a->n_heads, p.Bn), gk((a->Lk + 127) / 128, a->n_heads, p.Bn);
   dim3 gd((a->Lq + 3) / 4, a->n_heads, p.Bn);
   void* tok = nullptr;
+  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;          // (argument checks come before the profiling bracket opens)
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
   if (a->f32_split >= 2 && a->head_dim == 64) {
     hipLaunchKernelGGL(attn_f32_delta_k<64>, gd, dim3(256), 0, (hipStream_t)stream, p);
     if (a->f32_split == 2) {

@@ -351,7 +351,7 @@ extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, do
 
 extern "C" {
 
-int vm_version(void) { return 100; }
+int vm_version(void) { return 300; }      /* 300: round 3 (vm_gemm_args.b_nn / f32_split and vm_attn_f32_args.f32_split are part of the structs) */
 
 int vm_device_arch(char* name_host, int len) {
   int dev = 0;
@@ -492,19 +492,20 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
   const int fmode = a->f32_split == 0 ? f32_mode() : (a->f32_split == 1 ? 0 : a->f32_split);
 
+  // (every argument check comes BEFORE the profiling bracket opens: an early return must not leave an unmatched begin)
+  if (a->b_nn && (esz != 2 || a->out_dtype != VM_BF16 || p.ksplit > 1 || a->N % 8 || (int64_t)a->K * a->ldb * 2 >= (1ll << 31))) return VM_ERR_UNSUPPORTED;
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
   int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
-    if (esz != 2 || a->out_dtype != VM_BF16 || p.ksplit > 1 || a->N % 8 || (int64_t)a->K * a->ldb * 2 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
     { static int nt = -1; if (nt < 0) { const char* e = getenv("VM_NN_TILE"); nt = e ? atoi(e) : 192; }
       if (nt == 192 || nt == 256) big = nt; else if (!big) big = 256; }   // default 192: the 256-row NN form spills 15 VGPRs
     p.b_nn = 1;
   }
   if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
-    if (rc != VM_OK) return rc;
+    if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
   } else if (esz == 4 && bm64) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
     switch (fmode) {
@@ -577,7 +578,7 @@ int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_GEMM_BF16, stream, &tok);
   const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 1, stream);
-  if (rc != VM_OK) return rc;
+  if (rc != VM_OK) { vm_prof_end2_(VM_PROF_GEMM_BF16, stream, tok, 0.0, 0.0); return rc; }
   vm_prof_end2_(VM_PROF_GEMM_BF16, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2),
                 ((double)a->M + (double)a->N) * (a->K + 2.0 * a->K2) + (double)a->M * a->N * (a->out_dtype == VM_F32 ? 4 : 2));
   VM_LAUNCH_CHECK();

@@ -124,10 +124,10 @@ class ImageEncoderViT(nn.Module):
         self.gradient_checkpointing = False
         # arithmetic of the 12 blocks' fp32 GEMMs (~85 % of the grounding heads' GEMM time): split-bf16 with 3 products (each operand
         # as hi + lo bf16, the lo*lo term dropped: ~2^-16 relative per product, fp32 accumulation) instead of the heads' default 6.
-        # The encoder sits upstream of everything the 1e-4 parity bar is hardest on — the prompt gradients flow through the mask
-        # decoder only, which keeps 6 products; masks move by ~1e-5 and the encoder's own parameter gradients stay inside their
-        # 5e-4 bound (tests/test_model_gpu.py, test_truewidth_gpu.py run with this default). VM_ENC_F32_SPLIT=3 (or 1) restores 6
-        # products (exact f32 MFMA).
+        # The prompt gradients — what broke the 1e-4 bar of the fp32 islands under a PROCESS-WIDE mode 2 (9e-4 through iSAM) — flow
+        # through the mask decoder only, which keeps 6 products. Measured with this default at true width against the fp32 oracle
+        # (tests/test_config0_gpu.py, profiles/r3_parity_report.json): masks 1.3e-6, boxes 2.8e-7, discriminator 7.3e-7, the
+        # encoder's own parameter gradients 8e-7 .. 3.3e-6 (bound 1e-4). VM_ENC_F32_SPLIT=3 (or 1) restores 6 products (exact f32 MFMA).
         for m in self.blocks.modules():
             if isinstance(m, Linear):
                 m.f32_split = ENCODER_F32_SPLIT

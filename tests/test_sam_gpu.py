@@ -160,7 +160,7 @@ def test_sam_parameter_gradients_through_the_bucket_path_match_oracle(dev):
             if not p.requires_grad or gr is None or gr.norm() < 1e-7:     # (k_proj.bias: softmax is shift-invariant, gradient == 0)
                 continue
             assert p.grad is not None, name
-            assert rel(p.grad, 2 * gr) < 5e-4, (name, rel(p.grad, 2 * gr))
+            assert rel(p.grad, 2 * gr) < 1e-4, (name, rel(p.grad, 2 * gr))          # measured worst 1.2e-5 (three-product encoder blocks)
             worst = max(worst, (rel(p.grad, 2 * gr), name))
             checked += 1
         assert checked > 40
