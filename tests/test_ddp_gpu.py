@@ -108,3 +108,55 @@ def test_two_ranks_end_with_identical_parameters_equal_to_averaged_gradients(dev
             d = float((torch.from_numpy(p0[n]) - ref).norm() / ref.norm().clamp_min(1e-12))
             worst = max(worst, d)
     assert worst < 2e-3, worst           # (bf16 parameters: an ulp here and there from the order of the two-rank sum)
+
+
+def _rccl_worker(port, q):
+    """one rank on RCCL (torch 'nccl' backend on ROCm): the bucketed all-reduce is a real collective launch on RCCL's stream, overlapped
+    with backward, and must change nothing on one rank"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.optim import FlatAdamW
+    res = {}
+    for mode in ('plain', 'rccl'):
+        m = _model(dev)
+        ddp = BucketedGradAllReduce([p for p in m.parameters() if p.requires_grad], bucket_bytes=1 << 20, world_size=1,
+                                    force_collectives=(mode == 'rccl'))
+        assert ddp.collectives == (mode == 'rccl') and len(ddp.buckets) > 2
+        opt = FlatAdamW(ddp, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+        launched = []
+        if mode == 'rccl':
+            orig = dist.all_reduce
+            dist.all_reduce = lambda *a, **k: (launched.append(1), orig(*a, **k))[1]
+        try:
+            for step in range(3):
+                ddp.zero_grad()
+                _grads_of(m, _batch(dev, 300 + step))
+                ddp.finish()
+                opt.step()
+        finally:
+            if mode == 'rccl':
+                dist.all_reduce = orig
+        torch.cuda.synchronize()
+        res[mode] = ({n: p.detach().float().cpu().numpy() for n, p in m.named_parameters() if p.requires_grad}, len(launched), len(ddp.buckets))
+        ddp.remove()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_single_rank_rccl_path_equals_the_collective_free_path_bit_for_bit(dev):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    (plain, n0, _), (rccl, n1, nb) = res['plain'], res['rccl']
+    assert n0 == 0 and n1 == 3 * nb                      # every bucket went through RCCL in every step
+    assert plain.keys() == rccl.keys() and len(plain) > 20
+    for n in plain:
+        assert (plain[n] == rccl[n]).all(), n
