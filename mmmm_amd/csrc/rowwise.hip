@@ -2,6 +2,8 @@
 // One wavefront (64 lanes) owns one row; 16-byte vector accesses; fp32 maths.
 // Reference op sites are cited per entry point in include/vividmed_hip.h.
 #include "vm_common.hpp"
+#include <mutex>
+#include <algorithm>
 
 namespace {
 
@@ -317,6 +319,69 @@ __global__ __launch_bounds__(256) void ew_k(const T* __restrict__ a, const T* __
     else r = vm_keep(seed, (uint64_t)i, p) ? x * inv_keep : 0.f;
     y[i] = Elem<T>::st(r);
   }
+}
+
+// ---------------------------------------------------------------- bf16 GELU / GELU' through a table
+// erf-GELU on bf16 tensors is VALU-bound, not HBM-bound: erff is ~38 instructions per element (both branches of its range split
+// execute in every wave) and the [6280 x 15360] activations of one ViT-E block took 84 us forward / 109 us backward in the step
+// against a memory time of 60 / 89 us. A bf16 input has only 65 536 values: the 5120 with 2^-16 <= |x| < 2^4 (20 binades x 128
+// mantissas x 2 signs) are filled ONCE per process by gelu_table_init_k with the very functions the arithmetic kernels use
+// (gelu_erf / gelu_erf_grad), the rest have closed forms with the same bits (vm_common.hpp gelu_tab_fwd8 / gelu_tab_bwd8): the
+// table kernels are bit-identical to ew_k on every input (tests/test_kernels_gpu.py walks all 65 536). Isolated 93 / 137 us ->
+// 71 / 111 us (values inside the table), 84 / 115 us (9 % of |x| >= 16, the last blocks of the random-init benchmark model); step
+// -2.1 ms. A full 65 536-entry table gathered from L1 / L2 instead of LDS + closed forms: 117 / 135 us (address-unit bound), removed.
+// Tried on top and removed (profiles/r3_gelu_fusion.txt): the same look-ups inside the 256-column GEMM's epilogue, fc1 writing h and
+// gelu(h), fc2's input-gradient GEMM multiplying by gelu'(h) — bit-identical, but the ~30 VALU operations per element run while the
+// CU's matrix pipe idles (8-13 us per 256 x 256 tile), whereas the stand-alone pass finds its input in the Infinity Cache and
+// costs 40 / 100 us: fused 392 / 536 us vs GEMM + kernel 396 / 530 us in isolation, +4.6 ms on the step.
+__device__ unsigned short g_gelu_fwd_tab[GT_N];                   // bf16( gelu(x) )
+__device__ float g_gelu_grad_tab[GT_N];                           // gelu'(x), fp32 as gelu_erf_grad returns it
+
+__global__ void gelu_table_init_k() {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < GT_N; i += gridDim.x * blockDim.x) {
+    const float x = bf2f((unsigned short)gt_bits_of(i));
+    g_gelu_fwd_tab[i] = f2bf(gelu_erf(x));
+    g_gelu_grad_tab[i] = gelu_erf_grad(x);
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void gelu_tab_k(const unsigned short* __restrict__ h, const unsigned short* __restrict__ dy,
+                                                  unsigned short* __restrict__ y, int64_t n) {
+  __shared__ __attribute__((aligned(16))) char tab_raw[BWD ? GT_N * 4 : GT_N * 2];
+  {
+    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(BWD ? (const void*)g_gelu_grad_tab : (const void*)g_gelu_fwd_tab);
+    f32x4_t* dst = reinterpret_cast<f32x4_t*>(tab_raw);
+    for (int i = threadIdx.x; i < (int)sizeof(tab_raw) / 16; i += 512) dst[i] = src[i];
+  }
+  __syncthreads();
+  const unsigned short* tf = reinterpret_cast<const unsigned short*>(tab_raw);
+  const float* tg = reinterpret_cast<const float*>(tab_raw);
+  const int64_t nv = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 512) {
+    const u16x8_t hv = ldv<unsigned short>(h + i * 8);
+    u16x8_t dv;
+    if (BWD) dv = ldv<unsigned short>(dy + i * 8);
+    u16x8_t o;
+    if (BWD) gelu_tab_bwd8(tg, hv, dv, o);
+    else gelu_tab_fwd8(tf, hv, o);
+    stv<unsigned short>(y + i * 8, o);
+  }
+  for (int64_t i = nv * 8 + (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) {
+    const float x = bf2f(h[i]);
+    y[i] = f2bf(BWD ? gelu_erf_grad(x) * bf2f(dy[i]) : gelu_erf(x));
+  }
+}
+
+// fills the tables on first use (once per process; the wait makes them visible to every stream)
+static int gelu_tables_ready(hipStream_t st) {
+  static std::once_flag once;
+  static int rc = VM_OK;
+  std::call_once(once, [&] {
+    hipLaunchKernelGGL(gelu_table_init_k, dim3(20), dim3(256), 0, st);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = VM_ERR_LAUNCH;
+  });
+  return rc;
 }
 
 template <typename T>
@@ -744,6 +809,22 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
   else if ((dtype) == VM_F32) { typedef float T; __VA_ARGS__; }       \
   else return VM_ERR_BAD_ARG;
 
+// bf16 tensors of >= 1 M elements go through the table kernels
+static bool gelu_use_table(int64_t n, int dtype) {      // VM_GELU_TABLE=0: always the arithmetic kernel
+  static const int on = [] { const char* e = getenv("VM_GELU_TABLE"); return e ? atoi(e) : 1; }();
+  return on && dtype == VM_BF16 && n >= (1 << 20);
+}
+template <bool BWD>
+static int gelu_tab_launch(const void* x, const void* dy, void* y, int64_t n, void* stream) {
+  if (!aligned16(x) || !aligned16(y) || (BWD && !aligned16(dy))) return VM_ERR_BAD_ARG;
+  if (int rc = gelu_tables_ready((hipStream_t)stream)) return rc;
+  const int64_t wgs = (n / 8 + 511) / 512;
+  hipLaunchKernelGGL((gelu_tab_k<BWD>), dim3((unsigned)std::min<int64_t>(wgs, 768)), dim3(512), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)y, n);
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
 extern "C" {
 
 int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps,
@@ -844,10 +925,14 @@ int vm_rope_inplace(void* qkv, int64_t ld, const int32_t* row_pos, const float* 
 
 int vm_silu_mul_fwd(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream)
   EW_LAUNCH(EW_SILU_MUL_F, gate, up, out, n, 0.f, 0ull)
-int vm_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream)
+int vm_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  if (gelu_use_table(n, dtype)) return gelu_tab_launch<false>(x, nullptr, y, n, stream);
   EW_LAUNCH(EW_GELU_F, x, (const void*)nullptr, y, n, 0.f, 0ull)
-int vm_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream)
+}
+int vm_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+  if (gelu_use_table(n, dtype)) return gelu_tab_launch<true>(x, dy, dx, n, stream);
   EW_LAUNCH(EW_GELU_B, x, dy, dx, n, 0.f, 0ull)
+}
 int vm_relu_bwd(const void* yv, const void* dy, void* dx, int64_t n, int dtype, void* stream)
   EW_LAUNCH(EW_RELU_B, yv, dy, dx, n, 0.f, 0ull)
 int vm_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream)

@@ -137,6 +137,19 @@ __device__ __forceinline__ void vm_mask8(u16x8m_t& v, uint64_t h0, uint64_t h1, 
   v = __builtin_bit_cast(u16x8m_t, w);
 }
 
+// bf16 GELU tables (filled by rowwise.hip gelu_table_init_k, read by gelu_tab_k): all bf16 values
+// with 2^-16 <= |x| < 2^4 — 20 binades x 128 mantissas x 2 signs
+constexpr int GT_E_LO = 111, GT_E_HI = 130;                       // biased exponents covered
+constexpr int GT_HALF = (GT_E_HI - GT_E_LO + 1) * 128;            // entries per sign
+constexpr int GT_N = 2 * GT_HALF;
+__device__ __forceinline__ unsigned gt_bits_of(int idx) {         // inverse of gt_index
+  const unsigned sign = idx >= GT_HALF ? 0x8000u : 0u;
+  return sign | (unsigned)((idx % GT_HALF) + (GT_E_LO << 7));
+}
+__device__ __forceinline__ int gt_index(unsigned bits) {          // < 0: outside the table
+  const unsigned rel = (bits & 0x7FFFu) - (unsigned)(GT_E_LO << 7);
+  return rel < (unsigned)GT_HALF ? (int)(rel + ((bits & 0x8000u) ? GT_HALF : 0)) : -1;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -145,3 +158,84 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// gelu(h) / dy * gelu'(h) for the 8 bf16 values of one 16-byte chunk through the LDS copies of the tables. All eight look-ups are
+// issued before any is used (no per-element control flow). Outside the table the fp32 formulas (gelu_erf / gelu_erf_grad) collapse to closed forms that give the SAME bits:
+//   |x| >= 16 (finite): erff = +-1 exactly and exp(-x^2 / 2) underflows to 0 -> gelu = x | -0,  gelu' = 1 | +0;
+//   2^-125 <= |x| < 2^-16: 0.5 x (1 + erf) is within 1.2e-5 relative of 0.5 x, itself a bf16 value, and rounds onto it; likewise
+//     (0.5 + O(x)) dy onto 0.5 dy when that is a normal bf16 number;
+//   x = +-0: +-0 and 0.5.
+// What is left (bf16 denormals, inf, NaN, a denormal dy under a tiny x) takes the formula itself behind one branch per chunk.
+// (The random-init benchmark model needs the large-|x| form: its residual stream grows with depth, |h| >= 16 for 9 % of the last
+// blocks' pre-activations, and with the formula as the only fallback every wave ran erff for all eight elements.)
+__device__ __forceinline__ void gelu_tab_fwd8(const unsigned short* tab, const u16x8_t& h, u16x8_t& o) {
+  int idx[8];
+  unsigned short v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) idx[e] = gt_index(h[e]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = tab[max(idx[e], 0)];
+  int lo = idx[0];
+#pragma unroll
+  for (int e = 1; e < 8; ++e) lo = min(lo, idx[e]);
+  if (__all(lo >= 0)) {                                               // the whole wave inside the table (the normal case of a trained model)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e];
+    return;
+  }
+  bool rare = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned bits = h[e], mag = bits & 0x7FFFu;
+    const bool tiny = mag >= 0x100u && mag < (unsigned)(GT_E_LO << 7);
+    const bool big = mag >= (unsigned)((GT_E_HI + 1) << 7) && mag < 0x7F80u;
+    unsigned r = bits;                                               // +-0 -> +-0
+    if (tiny) r = bits - 0x80u;                                      // x / 2
+    if (big) r = (bits & 0x8000u) ? 0x8000u : bits;                  // -0 | x
+    o[e] = idx[e] >= 0 ? v[e] : (unsigned short)r;
+    rare |= idx[e] < 0 && !tiny && !big && mag != 0;
+  }
+  if (rare) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned mag = h[e] & 0x7FFFu;
+      if ((mag > 0 && mag < 0x100u) || mag >= 0x7F80u) o[e] = f2bf(gelu_erf(bf2f(h[e])));
+    }
+  }
+}
+__device__ __forceinline__ void gelu_tab_bwd8(const float* tab, const u16x8_t& h, const u16x8_t& dy, u16x8_t& o) {
+  int idx[8];
+  float g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) idx[e] = gt_index(h[e]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = tab[max(idx[e], 0)];
+  int lo = idx[0];
+#pragma unroll
+  for (int e = 1; e < 8; ++e) lo = min(lo, idx[e]);
+  if (__all(lo >= 0)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e] * bf2f(dy[e]));
+    return;
+  }
+  bool rare = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const unsigned bits = h[e], mag = bits & 0x7FFFu, dmag = dy[e] & 0x7FFFu;
+    const bool tiny = mag >= 0x100u && mag < (unsigned)(GT_E_LO << 7);
+    const bool big = mag >= (unsigned)((GT_E_HI + 1) << 7) && mag < 0x7F80u;
+    float ge = 0.5f;                                                 // +-0, tiny
+    if (big) ge = (bits & 0x8000u) ? 0.0f : 1.0f;
+    if (idx[e] >= 0) ge = g[e];
+    o[e] = f2bf(ge * bf2f(dy[e]));
+    rare |= idx[e] < 0 && ((!tiny && !big && mag != 0) || (tiny && dmag != 0 && dmag < 0x100u));
+  }
+  if (rare) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned mag = h[e] & 0x7FFFu, dmag = dy[e] & 0x7FFFu;
+      const bool tiny = mag >= 0x100u && mag < (unsigned)(GT_E_LO << 7);
+      if ((mag > 0 && mag < 0x100u) || mag >= 0x7F80u || (tiny && dmag != 0 && dmag < 0x100u)) o[e] = f2bf(gelu_erf_grad(bf2f(h[e])) * bf2f(dy[e]));
+    }
+  }
+}
+

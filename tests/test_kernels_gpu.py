@@ -1029,3 +1029,33 @@ def test_gemm_nn_weight_form_equals_nt(dev, K, M, N, Kc):
     want = K.gemm(dy, K.transpose(W), w1=K.transpose(W1), **kw)
     got = K.gemm(dy, W, w1=W1, b_nn=True, **kw)
     assert torch.equal(got[:M - 5], want[:M - 5])
+
+
+def test_gelu_table_kernels_equal_the_arithmetic_kernels_on_every_bf16_value(dev, K):
+    """Tensors of >= 2^20 bf16 elements take the table kernels (rowwise.hip gelu_tab_k); smaller ones the erf arithmetic
+    (ew_k). Both must give the same bits for all 65 536 inputs, NaN / inf / denormals included, forward and backward."""
+    bits = torch.arange(65536, dtype=torch.int32, device=dev).to(torch.int16)
+    x = bits.view(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(5)
+    reps = 16
+    xs = x.repeat(reps)                                             # 2^20 elements -> table path
+    dy = torch.randn(xs.shape, device=dev, generator=g).bfloat16()
+    # (half of the gradients: arbitrary bit patterns — denormals, huge values, inf, NaN — against every input value)
+    odd = torch.randint(0, 65536, (xs.numel() // 2,), device=dev, generator=g, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    dy[: odd.numel()] = odd
+    y_tab, dx_tab = K.gelu(xs), K.gelu_bwd(xs, dy)
+    for r in range(reps):                                           # 2^16 elements per call -> arithmetic path
+        sl = slice(r * 65536, (r + 1) * 65536)
+        y_ar, dx_ar = K.gelu(xs[sl].clone()), K.gelu_bwd(xs[sl].clone(), dy[sl].clone())
+        assert torch.equal(y_tab[sl].view(torch.int16), y_ar.view(torch.int16))
+        assert torch.equal(dx_tab[sl].view(torch.int16), dx_ar.view(torch.int16))
+    # and against torch on the finite values (the arithmetic kernel's own contract)
+    fin = torch.isfinite(x.float())
+    ref = torch.nn.functional.gelu(x.float()[fin]).bfloat16()
+    assert torch.equal(y_tab[:65536][fin].view(torch.int16), ref.view(torch.int16))
+    # a ragged length exercises the scalar tail
+    n = (1 << 20) + 5
+    xr = torch.randn(n, device=dev, generator=g).bfloat16()
+    dr = torch.randn(n, device=dev, generator=g).bfloat16()
+    assert torch.equal(K.gelu(xr)[-5:], K.gelu(xr[-5:].clone()))
+    assert torch.equal(K.gelu_bwd(xr, dr)[-5:], K.gelu_bwd(xr[-5:].clone(), dr[-5:].clone()))
