@@ -59,6 +59,10 @@ struct DownP {
 // workgroups, no reduce launch): 317.5 vs 317.8 ms at K <= 2048, 319.2 / 319.7 vs 317.8 ms at K <= 4096 — the factor is re-read per
 // 16 rows; (b) a four-stage DMA ring for the single-pass grids: 320.3 vs 320.5 ms. Kept: always split K (4 x 99 workgroups + reduce
 // at K = 1792 instead of 99 workgroups): -0.9 ms.
+// With dropout the projection is VALU-bound, not memory-bound ([6280 x 15360]: 35 us without the mask, 64 us with it): ~100 VALU
+// instructions per 8 elements, a third of them the hash's 32-bit multiplies (v_mul_lo_u32 issues at quarter rate). Eight waves per
+// workgroup (two per 16-row group, half a K-tile each) to overlap mask generation with the DMA: 64.6 vs 64.1 us — it is issue-bound,
+// not latency-bound; only a cheaper hash would help, and the hash is shared with the oracle and every other consumer of the mask.
 constexpr int DN_BM = 64;
 
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
