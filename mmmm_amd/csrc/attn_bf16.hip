@@ -336,6 +336,16 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_fwd_k(const AttnP p) {
   }
 }
 
+// Measured [r3], built and removed: the forward software-pipelined inside each wave (scores of tile t + 1 issued under the softmax of
+// tile t, every K / V fragment read one or two MFMAs ahead of its use, the order pinned by scheduling fences; K consumed one tile
+// ahead of V on the same four LDS tiles; bit-identical, 58 attention tests green): ViT-E 85-86 vs 82-83 us, decoder 66 vs 49 us.
+// A wave's own latencies are not what bounds the kernel — four waves per SIMD already cover them. Per round of 256 queries x 64
+// keys and CU the three pipes cost: LDS 16 waves x (16 K-fragment reads of 1 KiB + 28 transposed V reads of 512 B) = 480 KiB at
+// 128 B/clk = 3 840 cycles; VALU 4 waves x ~800 = 3 200 cycles per SIMD; matrix pipe 4 x 480 = 1 920. Measured ~7 900 cycles per
+// round: the three barely overlap (the barrier per tile puts a workgroup's waves into the same phase), and the largest is the LDS
+// read stream, which re-reads each K / V tile once per 16 queries. Halving it needs 32 queries per wave (two B operands per K
+// fragment: ~200 VGPRs, two waves per SIMD) — a different kernel.
+
 // ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
