@@ -15,6 +15,8 @@ Same module / parameter names and the same forward surface as the reference
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import torch
@@ -308,38 +310,74 @@ class CogVLMModel(nn.Module):
         return x
 
 
+LM_HEAD_LABEL_ROWS = os.environ.get('VM_LMHEAD_LABEL_ROWS', '1') != '0'
+
+
 class _LMHeadCE(torch.autograd.Function):
     """lm_head GEMM -> bf16 logits -> fp32 weighted CE, without an fp32 [T, vocab] round trip
-    (reference :701 `self.lm_head(h).float()` then _sample_weighted_ce :610-627)."""
+    (reference :701 `self.lm_head(h).float()` then _sample_weighted_ce :610-627).
+
+    Only rows that carry a label enter the loss (`ignore_index` -100 everywhere else: the image tokens, the prompt, the padding — 44 % of
+    the benchmark's rows), so only those rows go through the [rows x 32 064 x 4096] products: the rows are compacted (labelled ones
+    first, device-side — no host sync, the count stays on the device and the GEMMs skip the tiles behind it), the three GEMMs and the
+    two CE passes run on the compact rows, and the hidden-state gradient is scattered back (zero rows for the unlabelled ones, which is
+    what they get from the full-size product too). The per-row CE and the loss are assembled in the ORIGINAL row order: same bits as
+    the full-size form."""
 
     @staticmethod
     def forward(ctx, h, W, labels, weight, nrows):
         V, Kd = W.shape
         Vp = (V + 63) // 64 * 64
-        logits = torch.empty(h.shape[0], Vp, dtype=h.dtype, device=h.device)
+        M = h.shape[0]
+        valid = labels >= 0
+        n_valid_i = valid.sum()
+        compact = LM_HEAD_LABEL_ROWS and M >= 512
+        if compact:
+            pos = torch.cumsum(valid, 0) - 1                                         # row -> compact position (labelled rows)
+            # compact position -> row: labelled rows first, in order; the others fill the tail from the end (a permutation without a sort)
+            dest = torch.where(valid, pos, M - torch.cumsum(~valid, 0))
+            perm = torch.empty(M, dtype=torch.int64, device=h.device).scatter_(0, dest, torch.arange(M, device=h.device)).to(torch.int32)
+            inv = torch.where(valid, pos, torch.full_like(pos, -1)).to(torch.int32)
+            n_lab = n_valid_i.to(torch.int32).reshape(1)
+            cnt = torch.cat([n_lab, n_lab])                                          # {split, rows}: one segment of n_lab rows
+            hc = K.gather_rows(h, perm, M, nrows=n_lab)
+            lab_c = labels[perm.long()].contiguous()
+        else:
+            perm = inv = cnt = None
+            n_lab, hc, lab_c = nrows, h, labels
+        logits = torch.empty(M, Vp, dtype=h.dtype, device=h.device)
         if Vp > V:
             logits[:, V:].zero_()
-        K.gemm(h, W, out=logits[:, :V])
-        row_ce, lse = K.ce_fwd(logits, labels, V, nrows)
-        valid = labels >= 0
-        n_valid = valid.sum().clamp_min(1).to(torch.float32)
+        if compact:
+            K.gemm(hc, W, w1=W, counts=cnt, out=logits[:, :V])
+        else:
+            K.gemm(hc, W, out=logits[:, :V])
+        row_ce_c, lse = K.ce_fwd(logits, lab_c, V, n_lab)
+        row_ce = torch.where(valid, row_ce_c[pos.clamp_min(0)], torch.zeros((), device=h.device)) if compact else row_ce_c
+        n_valid = n_valid_i.clamp_min(1).to(torch.float32)
         w = torch.where(valid, weight.to(torch.float32), torch.zeros((), device=h.device))
         loss = torch.dot(row_ce, w) / n_valid
-        ctx.save_for_backward(h, W, labels, lse, w / n_valid, nrows, logits)
+        scale = w / n_valid
+        ctx.compact = compact
+        ctx.save_for_backward(hc, W, lab_c, lse, scale[perm.long()].contiguous() if compact else scale, n_lab, logits, cnt, inv)
         ctx.mark_non_differentiable(row_ce)
         return loss, row_ce
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dloss, _):
-        h, W, labels, lse, scale, nrows, logits = ctx.saved_tensors
+        hc, W, lab_c, lse, scale, n_lab, logits, cnt, inv = ctx.saved_tensors
         V = W.shape[0]
-        d = K.ce_bwd(logits, labels, lse, scale * dloss.to(torch.float32), V, nrows, out=logits)   # in place, pad cols = 0
+        d = K.ce_bwd(logits, lab_c, lse, scale * dloss.to(torch.float32), V, n_lab, out=logits)   # in place, pad cols = 0
         dh = dW = None
         if ctx.needs_input_grad[0]:
-            dh = K.gemm(d, K.transpose(W.detach(), pad_to=64))              # K = padded vocab
+            Wt = K.transpose(W.detach(), pad_to=64)                                                # K = padded vocab
+            if ctx.compact:
+                dh = K.gather_rows(K.gemm(d, Wt, w1=Wt, counts=cnt), inv)                          # unlabelled rows: zeros
+            else:
+                dh = K.gemm(d, Wt)
         if ctx.needs_input_grad[1]:
-            dW = K.gemm_tn(d[:, :V], h, nrows=nrows)
+            dW = K.gemm_tn(d[:, :V], hc, nrows=n_lab)
         return dh, dW, None, None, None
 
 

@@ -339,3 +339,40 @@ def test_side_stream_factor_gradients_match_main_stream(dev, lm):
         assert other.keys() == res[0].keys()
         for n in res[0]:
             assert torch.equal(res[0][n], other[n]), n
+
+
+def test_lm_head_on_labelled_rows_equals_the_full_product(dev):
+    """_LMHeadCE compacts the rows that carry a label (device-side, no sync) and runs lm_head + CE on those only. Against the full-size
+    form (VM_LMHEAD_LABEL_ROWS=0): loss, per-row CE and the hidden-state gradient bit-identical (a row's products do not depend on
+    the other rows), the weight gradient equal up to the order of its fp32 row sum."""
+    from mmmm_amd.models.cogvlm import modeling_cogvlm as mc
+    g = torch.Generator(device='cpu').manual_seed(11)
+    M, Kd, V = 1500, 256, 1000
+    h0 = torch.randn(M, Kd, generator=g).to(dev).bfloat16()
+    W0 = (torch.randn(V, Kd, generator=g) / 16).to(dev).bfloat16()
+    labels = torch.randint(0, V, (M,), generator=g)
+    labels[torch.rand(M, generator=g) < 0.45] = -100
+    labels[-37:] = -100
+    labels = labels.to(dev)
+    weight = (torch.rand(M, generator=g) + 0.5).to(dev)
+    nrows = torch.tensor([M - 37], dtype=torch.int32, device=dev)
+    res = {}
+    for mode in (False, True):
+        mc.LM_HEAD_LABEL_ROWS = mode
+        h = h0.clone().requires_grad_(True)
+        W = W0.clone().requires_grad_(True)
+        loss, row_ce = mc._LMHeadCE.apply(h, W, labels, weight, nrows)
+        loss.backward()
+        res[mode] = (loss.detach(), row_ce, h.grad, W.grad)
+    mc.LM_HEAD_LABEL_ROWS = True
+    full, comp = res[False], res[True]
+    assert torch.equal(full[0], comp[0])
+    assert torch.equal(full[1], comp[1])
+    assert torch.equal(full[2].view(torch.int16), comp[2].view(torch.int16))
+    assert (comp[2][labels < 0] == 0).all()
+    assert rel(comp[3], full[3]) < 2e-3
+    # all rows unlabelled: a zero loss and zero gradients, not a division by zero
+    h = h0.clone().requires_grad_(True)
+    loss, _ = mc._LMHeadCE.apply(h, W0, torch.full_like(labels, -100), weight, nrows)
+    loss.backward()
+    assert loss.item() == 0.0 and not h.grad.any()
