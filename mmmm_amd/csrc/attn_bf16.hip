@@ -345,6 +345,15 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_fwd_k(const AttnP p) {
 // round: the three barely overlap (the barrier per tile puts a workgroup's waves into the same phase), and the largest is the LDS
 // read stream, which re-reads each K / V tile once per 16 queries. Halving it needs 32 queries per wave (two B operands per K
 // fragment: ~200 VGPRs, two waves per SIMD) — a different kernel.
+// ... which was then built too (attn32_fwd_k: 4 waves x 2 groups of 16 queries, every K / V fragment feeding two MFMAs, 215-233 VGPRs,
+// two 4-wave workgroups per CU; bit-identical): ViT-E 79-84 vs 81-83 us, decoder 47-49 vs 46-49 us. So it is not the LDS stream
+// either. What the forward's 82 us consist of was then measured by knocking parts out (debug builds, tools/ubench notes in DESIGN
+// section 3): no K / V DMA 68 us, no softmax 65, no P V product 64, no barrier 73, no DMA and no softmax 53 — the parts ADD UP
+// (DMA 14 + softmax 17 + P V 18 + scores ~18 + barrier 9 + fixed ~8), nothing hides behind anything else, although the softmax is
+// VALU work and the products matrix work of (in the 4-wave form) unsynchronised waves on the same SIMD. Inside the softmax neither the
+// 17 quarter-rate exponentials (replaced by a multiply: 80 us) nor the four ds_bpermute round trips (replaced by
+// v_permlane16/32_swap: 82-84 us) matter; it is the ~100 plain VALU instructions per tile (a third of them moves and LDS address
+// arithmetic). The lever that is left is instruction count: tiles unrolled by two so that ring addresses are immediates, no copies.
 
 // ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
 template <int HD, int NW>
