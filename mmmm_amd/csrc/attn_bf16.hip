@@ -555,15 +555,22 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 1) void attn16_dkv_k(const 
       for (int jj = 0; jj < 2; ++jj) {
         const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sL + 32 * hq + 16 * jj + 4 * g);
         const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sD + 32 * hq + 16 * jj + 4 * g);
+        if (edge) {                                    // wave-uniform BRANCH around a second copy of the loop: as a flag inside one loop the compares and selects run on every tile
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pr_ = fast_exp2(__builtin_fmaf(sa[jj][r], sc, -l4[r] * LOG2E));
-          if (edge) {
+          for (int r = 0; r < 4; ++r) {
+            float pr_ = fast_exp2(__builtin_fmaf(sa[jj][r], sc, -l4[r] * LOG2E));
             const int qp = qq0 + 32 * hq + 16 * jj + 4 * g + r;
             pr_ = (qp < seqlen && (!p.causal || kpos <= qp)) ? pr_ : 0.f;
+            pa[jj][r] = pr_;
+            sa[jj][r] = pr_ * (dp[jj][r] - d4[r]);
           }
-          pa[jj][r] = pr_;
-          sa[jj][r] = pr_ * (dp[jj][r] - d4[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr_ = fast_exp2(__builtin_fmaf(sa[jj][r], sc, -l4[r] * LOG2E));
+            pa[jj][r] = pr_;
+            sa[jj][r] = pr_ * (dp[jj][r] - d4[r]);
+          }
         }
       }
       const bf16x8_t pf = pack2(pa[0], pa[1]);
