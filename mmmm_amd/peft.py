@@ -46,15 +46,17 @@ class PeftModel:
         return self
 
     def load_adapter(self, model_id, adapter_name: str = 'default', is_trainable: bool = False, strict: bool = True):
-        """reference call sites: scripts/cli.py:87, mmmm.py:154-155. `is_trainable=False` freezes every adapter / saved-module
-        tensor after loading (PEFT's inference mode)."""
+        """reference call sites: scripts/cli.py:87, mmmm.py:154-155. The 'default' adapter always exists by the time either runs
+        (`get_peft_model` registered it, cli.py:82-84), and for an EXISTING adapter PEFT's `load_adapter` only loads the weights —
+        its `inference_mode` freeze applies to an adapter name it has to create. So `requires_grad` is left exactly as it was
+        (LoRA factors, `modules_to_save` copies and the unfrozen heads stay trainable through `load_default_adapter`, whose
+        `is_trainable` defaults to False); `is_trainable=False` only puts the model in eval mode, as PEFT does."""
         if adapter_name != 'default':
             raise NotImplementedError('one adapter ("default") per model on this path')
         from .models.checkpoint import load_adapter
         result = load_adapter(self.model, Path(model_id), strict=strict)
         if not is_trainable:
-            for p in self.model.parameters():
-                p.requires_grad_(False)
+            self.model.eval()
         return result
 
     def save_pretrained(self, save_directory, **kwargs):

@@ -90,7 +90,8 @@ def test_cli_peft_sequence_from_lora_yaml(tmp_path):
     trainable = {n for n, p in m.named_parameters() if p.requires_grad}
     assert 'model.layers.0.self_attn.language_expert_dense.lora_A.default.weight' in trainable and 'lm_head.weight' in trainable
     assert not any(n.startswith(('sam.', 'isam_model.')) for n in trainable) and 'vg_proj.0.weight' in trainable
-    # save -> perturb -> load_default_adapter (mmmm.py:154-155: <ckpt_dir>/adapter) restores; a non-trainable load freezes
+    # save -> perturb -> load_default_adapter (mmmm.py:154-155: <ckpt_dir>/adapter) restores the weights; the adapter already exists,
+    # so PEFT leaves requires_grad alone (its inference-mode freeze is for adapter names it creates) and only calls eval()
     with torch.no_grad():
         lin.B.normal_()
     want = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
@@ -103,7 +104,8 @@ def test_cli_peft_sequence_from_lora_yaml(tmp_path):
     for n, p in m.named_parameters():
         if n in want:
             assert torch.equal(p.detach(), want[n]), n
-    assert not any(p.requires_grad for p in m.parameters())          # peft: is_trainable defaults to False
+    assert {n for n, p in m.named_parameters() if p.requires_grad} == set(want) and not m.training
+    m.train()
     # `fit` passes is_trainable=True (cli.py:87)
     m2, _ = _build('phase-vg')
     lc = LoraConfig(**lora_yaml)
