@@ -432,8 +432,10 @@ def main():
     if args.fp8:
         from mmmm_amd.models.lora import enable_fp8
         n_fp8 = enable_fp8(model)
-    trainable = [p for p in model.parameters() if p.requires_grad]
-    ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist)
+    from mmmm_amd.ddp import grad_production_order
+    trainable = grad_production_order(model)       # heads, lm_head, norm, decoder 31..0, embed_tokens, GLU, ViT-E 62..0, patch embedding
+    assert len(trainable) == sum(p.requires_grad for p in model.parameters())
+    ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist, order='given')
     from mmmm_amd.optim import FlatAdamW
     if args.optimizer == 'flat':       # gradient clip (1.0) + AdamW in one kernel per bucket (mmmm_amd/optim.py)
         opt = FlatAdamW(ddp, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0)

@@ -13,6 +13,7 @@
 //     (two half-tiles may remain outstanding), never vmcnt(0) inside the steady-state loop.
 //   * the two waves of a SIMD (wave rows wm = 0 / 1) are staggered by one barrier interval so that one is in its
 //     MFMA segment while the other is in its LDS-read / DMA-issue segment.
+#include <mutex>
 #include "vm_common.hpp"
 #include "gemm_common.hpp"
 #include "vm_tile.hpp"
@@ -400,16 +401,18 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   if (tile_rows != 256 && tile_rows != 192) return VM_ERR_BAD_ARG;
   p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
   p.tiles_n = (p.N + 255) / 256;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;          // (called from the main thread and from autograd's backward thread)
+  static bool attr_ok = false;
+  std::call_once(attr_once, [] {
     const void* fns[10] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
                           (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
                           (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>,
                           (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>};
-    for (const void* f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) != hipSuccess) return VM_ERR_LAUNCH;
-    attr_set = true;
-  }
+    bool ok = true;
+    for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) == hipSuccess;
+    attr_ok = ok;
+  });
+  if (!attr_ok) return VM_ERR_LAUNCH;
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   hipStream_t st = (hipStream_t)stream;
 #define VM_G256_LAUNCH(O, M_, F_) hipLaunchKernelGGL((gemm256_k<O, M_, F_>), grid, block, LDS_BYTES2, st, p)

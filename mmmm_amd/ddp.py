@@ -6,9 +6,20 @@ backend is RCCL on ROCm. Only the trainable set is exchanged (LoRA factors + mod
 parameters = 1.58 GB bf16); the frozen 17.6 B base weights are replicated.
 
 Design for MI355X xGMI (fully connected, 7 links x ~153 GB/s per GPU): few LARGE buckets (default 256 MiB) so
-each collective runs at link bandwidth, filled in REVERSE parameter order so that a bucket is complete — and its
-all-reduce is enqueued on RCCL's stream — as soon as the backward of the layers it covers has finished. Gradients
-live directly inside the flat bucket buffers (param.grad is a view), so there is no pack/unpack copy.
+each collective runs at link bandwidth, filled in the order in which BACKWARD PRODUCES the gradients so that a bucket is
+complete — and its all-reduce is enqueued on RCCL's stream — as soon as the backward of the layers it covers has finished.
+That order is NOT the reverse of the registration order for this model: `CogVLMModel` registers `embed_tokens, layers, norm,
+vision` and `MMMMForCausalLM` adds `lm_head, sam, isam_model, vg_proj`, while the data flows vision -> embed -> layers -> norm
+-> lm_head -> heads. `grad_production_order(model)` states the order from the module structure (heads, lm_head, norm, decoder
+31..0, embed_tokens, GLU adapter, ViT-E 62..0, patch embedding: SURVEY §8e) and is what bench.py / the Lightning shell pass
+(`order='given'`); `order='reverse'` (reverse registration, torch DDP's first-iteration heuristic) stays the default for plain
+networks. Every step records the order in which slots became final (`ready_log`) and when each bucket was launched
+(`launch_log`), so `exposed_report()` can say how many bucket bytes were issued after backward's last gradient — the quantity
+the overlap is judged on — without any hardware (tests/test_ddp_cpu.py). The last bucket of a key is kept small (`tail_bytes`):
+whatever completes with the step's LAST gradient (ViT-E layer 0 / the patch embedding) cannot overlap with anything.
+Gradients live directly inside the flat bucket buffers (param.grad is a view), so there is no pack/unpack copy.
+The 1/world averaging is not a pass of its own: `finish()` leaves the SUM in the buckets and `grad_scale` = 1/world pending;
+`optim.FlatAdamW` folds it into the clip coefficient its kernel applies anyway (`clip_grad_norm_` folds it likewise).
 
 Unused-parameter hazard (reference mmmm.py:263-278 runs dummy SAM forwards so that every rank produces every
 gradient): here every bucket is reduced every step in a fixed order; a parameter that received no gradient
@@ -22,6 +33,95 @@ import torch
 import torch.distributed as dist
 
 from .param import no_weight_decay
+
+
+def production_stages(model) -> list:
+    """Trainable parameters of an `MMMMForCausalLM` (or any module tree with the same child names) grouped into the stages whose
+    gradients backward produces together, in production order: stages in REVERSE forward order, inside a stage reverse registration
+    order (~ reverse use order). Forward order (mmmm.py:296-352 -> modeling_cogvlm.py:659-710, visual.py:193-210):
+    vision.patch_embedding, vision.transformer.layers 0..62, the rest of vision (GLU adapter, boi / eoi), embed_tokens, layers 0..31,
+    norm, lm_head, then the grounding heads (vg_proj feeds isam_model, then sam: mmmm.py `visual_grounding`). Parameters outside
+    these stages keep reverse registration order at the end."""
+    stages = []                                    # forward order
+
+    def sub(root, path):
+        m = root
+        for name in path.split('.'):
+            m = getattr(m, name, None)
+            if m is None:
+                return None
+        return m
+
+    core = sub(model, 'model') or model
+    vis = sub(core, 'vision')
+    if vis is not None:
+        pe = sub(vis, 'patch_embedding')
+        if pe is not None:
+            stages.append(list(pe.parameters()))
+        tl = sub(vis, 'transformer.layers')
+        if tl is not None:
+            stages.extend(list(l.parameters()) for l in tl)
+        stages.append(list(vis.parameters()))      # what is left of the tower (deduplicated below)
+    m = sub(core, 'embed_tokens')
+    if m is not None:
+        stages.append(list(m.parameters()))
+    dl = sub(core, 'layers')
+    if dl is not None:
+        stages.extend(list(l.parameters()) for l in dl)
+    for root, name in ((core, 'norm'), (model, 'lm_head'), (model, 'vg_proj'), (model, 'isam_model'), (model, 'sam')):
+        m = sub(root, name)
+        if m is not None:
+            stages.append(list(m.parameters()))
+    seen, fwd = set(), []
+    for st in stages:
+        st = [p for p in st if id(p) not in seen]
+        seen.update(id(p) for p in st)
+        fwd.append(st)
+    rest = [p for p in model.parameters() if id(p) not in seen]
+    out = [list(reversed(st)) for st in reversed(fwd)] + [list(reversed(rest))]
+    return [[p for p in st if p.requires_grad] for st in out]
+
+
+def grad_production_order(model) -> list:
+    """`production_stages` flattened: the `params` argument of `BucketedGradAllReduce(..., order='given')`"""
+    return [p for st in production_stages(model) for p in st]
+
+
+def plan_buckets(seq, bucket_bytes: int = 256 << 20, tail_bytes: int | None = None) -> list:
+    """[(key, [params])] for parameters `seq` GIVEN IN GRADIENT-PRODUCTION ORDER; works on meta tensors (no allocation).
+    key = (dtype, device, decayed?): decayed and undecayed parameters (param.NoWeightDecayParameter) never share a bucket, so the
+    fused AdamW launch of a bucket has ONE decay value. A bucket is closed when the next parameter of its key would overflow it;
+    buckets are ordered by the production index of their LAST parameter — the moment they complete — so launching them strictly
+    in list order never holds a finished bucket behind an unfinished one (the fp32 heads' remainder bucket completes early in
+    backward although it is closed last). The final bucket of every key is split so that its trailing part is <= tail_bytes."""
+    if tail_bytes is None:
+        tail_bytes = max(bucket_bytes // 4, 1)
+    nbytes = lambda p: (p.numel() + 7) // 8 * 8 * p.element_size()
+    cur: dict = {}
+    closed: list = []                                # (completion index, key, params)
+    for i, p in enumerate(seq):
+        key = (p.dtype, p.device, not no_weight_decay(p))
+        lst, size = cur.get(key, ([], 0))
+        if lst and size + nbytes(p) > bucket_bytes:
+            closed.append((lst[-1][0], key, [q for _, q in lst]))
+            lst, size = [], 0
+        lst.append((i, p))
+        cur[key] = (lst, size + nbytes(p))
+    for key, (lst, size) in cur.items():
+        if not lst:
+            continue
+        if size > tail_bytes and len(lst) > 1:      # split: [head][tail <= tail_bytes] (at least the last parameter)
+            acc, cut = 0, len(lst) - 1
+            for j in range(len(lst) - 1, 0, -1):
+                if acc + nbytes(lst[j][1]) > tail_bytes and j < len(lst) - 1:
+                    break
+                acc += nbytes(lst[j][1])
+                cut = j
+            closed.append((lst[cut - 1][0], key, [q for _, q in lst[:cut]]))
+            lst = lst[cut:]
+        closed.append((lst[-1][0], key, [q for _, q in lst]))
+    closed.sort(key=lambda t: t[0])
+    return [(key, lst) for _, key, lst in closed]
 
 
 @dataclass(eq=False)
@@ -44,8 +144,19 @@ class BucketedGradAllReduce:
     `p._vm_grad_ready(p)` only REGISTERS the stream the kernel ran on; it never counts."""
 
     def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None,
-                 force_collectives: bool = False, sync_params: bool = True):
+                 force_collectives: bool = False, sync_params: bool = True, order: str = 'reverse', tail_bytes: int | None = None,
+                 defer_average: bool = False):
+        """`order`: 'reverse' = `params` are in registration order, gradients are expected in the reverse of it; 'given' = `params`
+        are already in gradient-production order (`grad_production_order(model)`). `defer_average`: finish() leaves the SUM over
+        ranks in the buckets and `grad_scale` = 1/world for the consumer to fold into its own pass (FlatAdamW sets this)."""
+        assert order in ('reverse', 'given')
         self.params = [p for p in params if p.requires_grad]
+        self._seq = list(reversed(self.params)) if order == 'reverse' else list(self.params)
+        self.tail_bytes = tail_bytes
+        self.defer_average = defer_average
+        self.grad_scale = 1.0                     # pending factor on the bucket contents (1/world after a deferred finish())
+        self.ready_log: list = []                 # ids of the parameters in the order their slots became final (this step)
+        self.launch_log: list = []                # (bucket index, len(ready_log) at launch, launched by finish()?)
         self.pg = process_group
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -81,23 +192,7 @@ class BucketedGradAllReduce:
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):
-        # reverse registration order ~ the order in which backward produces gradients; decayed and undecayed parameters
-        # (param.NoWeightDecayParameter) never share a bucket, so the fused AdamW launch of a bucket has ONE decay value
-        cur: dict[tuple, tuple[list, int]] = {}
-        plan: list[tuple[tuple, list]] = []
-        for p in reversed(self.params):
-            key = (p.dtype, p.device, not no_weight_decay(p))
-            lst, size = cur.get(key, ([], 0))
-            nbytes = p.numel() * p.element_size()
-            if lst and size + nbytes > bucket_bytes:
-                plan.append((key, lst))
-                lst, size = [], 0
-            lst.append(p)
-            cur[key] = (lst, size + nbytes)
-        for key, (lst, _) in cur.items():
-            if lst:
-                plan.append((key, lst))
-        for (dtype, device, decay), lst in plan:
+        for (dtype, device, decay), lst in plan_buckets(self._seq, bucket_bytes, self.tail_bytes):
             n = sum((p.numel() + 7) // 8 * 8 for p in lst)       # 16-byte aligned slots
             buf = torch.zeros(n, dtype=dtype, device=device)
             b = _Bucket(buffer=buf, params=lst, decay=decay)
@@ -108,6 +203,25 @@ class BucketedGradAllReduce:
                 off += (p.numel() + 7) // 8 * 8
             b.pending = len(lst)
             self.buckets.append(b)
+
+    # -- overlap bookkeeping ---------------------------------------------------------------------
+    def exposed_report(self) -> dict:
+        """From the last step's logs: per bucket the position in `ready_log` at which it was launched; `exposed_bytes` = bytes of the
+        buckets launched when the step's LAST gradient was already final (by that gradient's own hook or by finish()): nothing of
+        backward is left to hide their all-reduce. `inversions` = buckets that were complete before an earlier-indexed bucket was
+        (they waited behind it): 0 when the bucket order matches the production order."""
+        n = len(self.ready_log)
+        pos = {pid: i for i, pid in enumerate(self.ready_log)}
+        complete_at = [max((pos.get(id(p), n) for p in b.params), default=0) for b in self.buckets]
+        rows, exposed, inv = [], 0, 0
+        for bi, at, by_finish in self.launch_log:
+            nb = self.buckets[bi].buffer.numel() * self.buckets[bi].buffer.element_size()
+            late = by_finish or at >= n
+            exposed += nb if late else 0
+            waited = at - 1 - complete_at[bi] if not by_finish else n - 1 - complete_at[bi]
+            inv += 1 if waited > 0 else 0
+            rows.append({'bucket': bi, 'bytes': nb, 'launched_at': at, 'complete_at': complete_at[bi], 'by_finish': by_finish})
+        return {'n_ready': n, 'buckets': rows, 'exposed_bytes': exposed, 'inversions': inv, 'total_bytes': self.total_bytes}
 
     # -- replica consistency -------------------------------------------------------------------
     @torch.no_grad()
@@ -207,6 +321,7 @@ class BucketedGradAllReduce:
                                    'collectives on, run exactly one backward pass per finish() (no local gradient accumulation)')
             return
         self._ready.add(id(p))
+        self.ready_log.append(id(p))
         b = self.buckets[self._bucket_of[id(p)]]
         b.pending -= 1
         if p.is_cuda:       # backward nodes run on the stream of their forward (the grounding heads use a side stream)
@@ -215,7 +330,8 @@ class BucketedGradAllReduce:
             self._step_streams.add(st)
         self._launch_ready()
 
-    def _launch(self, b: _Bucket):
+    def _launch(self, b: _Bucket, by_finish: bool = False):
+        self.launch_log.append((self._next, len(self.ready_log), by_finish))
         if b.buffer.is_cuda:
             from . import functional as Fh
             Fh.flush_wgrad_queue()          # factor gradients still queued for a grouped launch belong to this (or an earlier) bucket
@@ -249,7 +365,7 @@ class BucketedGradAllReduce:
             from . import functional as Fh
             Fh.flush_wgrad_queue()
         while self._next < len(self.buckets):
-            self._launch(self.buckets[self._next])
+            self._launch(self.buckets[self._next], by_finish=True)
             self._next += 1
         for b in self.buckets:
             if b.work is not None:
@@ -273,13 +389,18 @@ class BucketedGradAllReduce:
                 consumer.wait_stream(st)
         self._step_streams.clear()
         if self.collectives and self.world_size > 1:
-            inv = 1.0 / self.world_size
-            for b in self.buckets:
-                b.buffer.mul_(inv)
+            if self.defer_average:
+                # the buckets hold the SUM over ranks; whoever reads them next folds 1/world into a pass it makes anyway
+                # (optim.FlatAdamW: into the clip coefficient of vm_adamw; clip_grad_norm_: into its one scale per bucket)
+                self.grad_scale = 1.0 / self.world_size
+            else:
+                inv = 1.0 / self.world_size
+                for b in self.buckets:
+                    b.buffer.mul_(inv)
 
     def abort_step(self):
         """Bring the exchange back to a clean state after a forward / backward pass that RAISED (bench.py's calibration retries after
-        an out-of-memory error): wait for the device, drop the references the backward pass parked (functional._HELD — the engine
+        an out-of-memory error): wait for the device, drop the references the backward pass parked (functional._HELD_BY_TASK — the engine
         discards its final callbacks when a pass raises), forget the side stream's lag ring, zero the buckets AND the fp32 side
         accumulators (partial norm-gradient sums of the aborted pass: `zero_grad` alone leaves them to be folded into the next
         step's gradients), reset the readiness counters."""
@@ -315,6 +436,9 @@ class BucketedGradAllReduce:
         self._next = 0
         self._ready.clear()
         self._step_streams.clear()
+        self.ready_log = []
+        self.launch_log = []
+        self.grad_scale = 1.0
 
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
@@ -324,10 +448,11 @@ class BucketedGradAllReduce:
         for b in self.buckets:
             v = torch.linalg.vector_norm(b.buffer, 2, dtype=torch.float32)
             sq = v * v if sq is None else sq + v * v
-        total = sq.sqrt()
-        coef = torch.clamp(max_norm / (total + eps), max=1.0)
+        total = sq.sqrt() * self.grad_scale          # norm of the AVERAGED gradient (a deferred 1/world is still pending)
+        coef = torch.clamp(max_norm / (total + eps), max=1.0) * self.grad_scale
         for b in self.buckets:
             b.buffer.mul_(coef.to(b.buffer.dtype))
+        self.grad_scale = 1.0
         return total
 
     def remove(self):

@@ -7,6 +7,7 @@ libvividmed_hip.so; there is no eager/PyTorch fallback (a CPU tensor raises in m
 from __future__ import annotations
 
 import os
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -114,10 +115,9 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
 _WGRAD_STREAMS: dict = {}
 _WGRAD_EVENTS: dict = {}
 SIDE_LAG = int(os.environ.get('VM_SIDE_LAG', '24'))          # forked calls the side stream may trail the main stream by (~2 transformer layers)
-_HELD: list = []              # tensors kept referenced until the running backward pass ends (_hold_until_backward_ends)
 
 
-_HELD_TASK = [None]          # graph-task id of the backward pass `_HELD` belongs to
+_HELD_BY_TASK: dict = {}     # graph-task id -> tensors held until that backward pass ends
 
 
 def _hold_until_backward_ends(t: torch.Tensor):
@@ -133,16 +133,25 @@ def _hold_until_backward_ends(t: torch.Tensor):
     callbacks when a backward pass raises (an out-of-memory error in the calibration steps of bench.py), and a registration keyed on
     "the list is empty" would then never happen again — every later step would append its dy tensors and free none."""
     task = torch._C._current_graph_task_id()
-    if task != _HELD_TASK[0]:
-        _HELD.clear()                     # (left over from a pass that raised)
-        _HELD_TASK[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(_release_held)
-    _HELD.append(t)
+    lst = _HELD_BY_TASK.get(task)
+    if lst is None:
+        # one list per backward pass: a nested pass (reentrant checkpoint, double backward) must not drop the outer pass's tensors.
+        # The list of a pass that RAISED is never released by its callback (the engine drops it): `_drop_stale_held` (the next
+        # forward pass) or ddp.abort_step removes it.
+        lst = _HELD_BY_TASK[task] = []
+        torch.autograd.Variable._execution_engine.queue_callback(lambda task=task: _HELD_BY_TASK.pop(task, None))
+    lst.append(t)
 
 
 def _release_held():
-    _HELD.clear()
-    _HELD_TASK[0] = None
+    _HELD_BY_TASK.clear()
+
+
+def _drop_stale_held():
+    """called from forward ops: outside any backward pass (graph-task id < 0 — a checkpoint recompute runs INSIDE one) nothing can be
+    legitimately held, so whatever is left belongs to passes that raised"""
+    if _HELD_BY_TASK and torch._C._current_graph_task_id() < 0:
+        _HELD_BY_TASK.clear()
 
 
 def abort_backward_state():
@@ -152,6 +161,9 @@ def abort_backward_state():
         ring.clear()
     _WGRAD_QUEUE.clear()
     _WGRAD_QUEUE_STATE[0] = _WGRAD_QUEUE_STATE[1] = None
+    if '_U_STASH' in globals():
+        _U_STASH.clear()
+        _U_STASH_TASK[0] = None
 
 
 # [r3] OFF by default: with the chip saturated by the main stream the side stream no longer hides anything (round 2 already measured
@@ -230,6 +242,10 @@ def _queue_wgrad(param, ready, W, S, transpose_out, counts, seg, alpha, drop_p, 
             # whatever is still queued when this backward pass ends goes out then (callers may read .grad right after backward())
             torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_queue)
         _WGRAD_QUEUE_STATE[0], _WGRAD_QUEUE_STATE[1] = task, st
+    if any(q[1] is param for q in _WGRAD_QUEUE):
+        # the same slot twice in one grouped launch (a LoRA linear applied twice within 24 queued factors: shared modules, depth-1 models):
+        # two workgroups would read-modify-write one tile unsynchronised — the earlier items go out first
+        flush_wgrad_queue()
     _WGRAD_QUEUE.append(((W, S, param.grad, transpose_out, counts, seg, alpha, drop_p, seed), param, ready))
     if len(_WGRAD_QUEUE) >= hip.TN_GROUP_MAX:
         flush_wgrad_queue()
@@ -260,7 +276,9 @@ def flush_wgrad_queue():
 # recomputed forward saved: a saved parameter then is a plain tensor without `.grad` and without the bucket's tags, and the kernels
 # would fall back to returning gradient tensors for AccumulateGrad — every layer of the reference's own checkpoint-everything mode
 # took that path (found when the grouped launch made the two paths differ in the last bit: tools/debug_group_inputs.py).
-PARAM_BY_PTR: dict = {}
+# Weak references: a model that goes away takes its entries (and through `.grad` its flat bucket buffers) with it; a parameter whose
+# storage has moved since registration (`.to()`, a load replacing `.data`) is no longer found under its old address.
+PARAM_BY_PTR = weakref.WeakValueDictionary()
 
 
 def _real_param(p):
@@ -268,7 +286,7 @@ def _real_param(p):
     if p is None or getattr(p, '_vm_grad_ready', None) is not None:
         return p
     q = PARAM_BY_PTR.get(p.data_ptr())
-    return q if (q is not None and q.shape == p.shape and q.dtype == p.dtype) else p
+    return q if (q is not None and q.data_ptr() == p.data_ptr() and q.shape == p.shape and q.dtype == p.dtype) else p
 
 
 def _direct_slot(param):
@@ -461,7 +479,7 @@ class _Linear(Function):
                     fuse_b = bready is not None and b.grad is not None and b.grad.dtype == torch.float32 and b.grad.is_contiguous()
 
                     def run(W=W, wready=wready, b=b, bready=bready, fuse_b=fuse_b):
-                        if F32_TN_WGRAD and meta.f32_split != 1 and K.gemm_tn_f32_supported(dy, x, W.grad):
+                        if F32_TN_WGRAD and K.gemm_tn_f32_supported(dy, x, W.grad, meta.f32_split):
                             # TN form: dy and x as they are, the bias gradient from the tiles the kernel stages anyway
                             K.gemm_tn_f32(dy, x, W.grad, colsum_out=b.grad if fuse_b else None, f32_split=meta.f32_split)
                         else:
@@ -505,6 +523,8 @@ class _Linear(Function):
 def linear(x, W0, *, meta: LinearMeta | None = None, Wt0=None, b0=None, A0=None, B0=None,
            W1=None, Wt1=None, b1=None, A1=None, B1=None, residual=None, counts=None):
     meta = meta or LinearMeta()
+    if _HELD_BY_TASK:
+        _drop_stale_held()
     return _Linear.apply(meta, x, residual, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
 
 
@@ -654,8 +674,14 @@ _U_STASH: dict = {}
 FUSE_EW_LORA = int(os.environ.get('VM_FUSE_EW_LORA', '0'))
 
 
+_U_STASH_TASK = [None]
+
+
 def _stash_u(dy: torch.Tensor, Bt: torch.Tensor, u: torch.Tensor):
-    if not _U_STASH:
+    task = torch._C._current_graph_task_id()
+    if task != _U_STASH_TASK[0]:          # keyed on the backward pass, not on "the table is empty": a pass that raised leaves entries behind
+        _U_STASH.clear()
+        _U_STASH_TASK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_U_STASH.clear)
     _U_STASH[(dy.data_ptr(), Bt.data_ptr())] = (u, dy.shape)
 
@@ -965,7 +991,6 @@ def overwrite_rows_(base, src, idx):
 
 
 # ----------------------------------------------------------------------------- trilinear up-sampling of mask logits
-UPSAMPLE_HIP = os.environ.get('VM_UPSAMPLE_HIP', '1') == '1'      # 0: ATen's interpolate on the GPU as well (A/B measurements)
 
 
 class _UpsampleTrilinear(Function):
@@ -981,17 +1006,16 @@ class _UpsampleTrilinear(Function):
 
 
 def upsample_trilinear(x: torch.Tensor, size) -> torch.Tensor:
-    """F.interpolate(x, size, mode='trilinear') for [..., d, h, w] volumes (segvol/modeling/sam.py:57-87). fp32 device tensors
-    go through the HIP kernels (gather-form, deterministic backward); anything else through ATen."""
+    """F.interpolate(x, size, mode='trilinear') for fp32 device volumes [..., d, h, w] (segvol/modeling/sam.py:57-87) through the HIP
+    kernels (gather-form, deterministic backward). No other path: anything else raises, like every wrapper of this module."""
     size = tuple(int(v) for v in size)
-    if UPSAMPLE_HIP and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 4 and x.numel() > 0:
-        lead = x.shape[:-3]
-        y = _UpsampleTrilinear.apply(x.reshape(-1, *x.shape[-3:]).contiguous(), size)
-        return y.view(*lead, *size)
-    import torch.nn.functional as F
-    x5 = x.reshape(1, -1, *x.shape[-3:]) if x.dim() != 5 else x
-    y = F.interpolate(x5, size, mode='trilinear')
-    return y.view(*x.shape[:-3], *size)
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 4):
+        raise TypeError(f'upsample_trilinear: fp32 device tensor [..., d, h, w] expected, got {x.dtype} {tuple(x.shape)} on {x.device}')
+    lead = x.shape[:-3]
+    if x.numel() == 0:                         # no prompts: nothing to interpolate, the result is empty too
+        return x.new_zeros(*lead, *size) + 0 * x.sum()
+    y = _UpsampleTrilinear.apply(x.reshape(-1, *x.shape[-3:]).contiguous(), size)
+    return y.view(*lead, *size)
 
 
 # ----------------------------------------------------------------------------- Dice + focal loss of mask logits

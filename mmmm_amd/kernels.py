@@ -5,6 +5,8 @@ Every function enqueues on the current torch stream and returns immediately; the
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import functools
 import math
@@ -181,9 +183,26 @@ def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Ten
     return out
 
 
+def _f32_mode_from_env() -> int:
+    try:
+        v = int(os.environ.get('VM_F32_SPLIT', '3'))
+    except ValueError:
+        v = 3
+    return v if v in (0, 2, 3) else 3
+
+
+_F32_MODE = [_f32_mode_from_env()]          # mirror of the library's process default (gemm.hip f32_mode(): same rule, same variable)
+
+
 def gemm_f32_mode(mode: int):
     """arithmetic of vm_gemm_f32 (vm_gemm_f32_mode): 0 exact f32 MFMA, 2 split-bf16 in registers with 3 products, 3 with 6 (default)"""
     hip.call('vm_gemm_f32_mode', mode)
+    _F32_MODE[0] = mode
+
+
+def f32_mode_resolved(f32_split: int = 0) -> int:
+    """the arithmetic a call with `f32_split` gets: 0 exact, 2 / 3 split-bf16 (f32_split 0 = the process default, 1 = exact)"""
+    return _F32_MODE[0] if f32_split == 0 else (0 if f32_split == 1 else f32_split)
 
 
 
@@ -308,8 +327,10 @@ def gemm_tn(X: torch.Tensor, Y: torch.Tensor, *, counts: torch.Tensor | None = N
 VM_F32_ = hip.VM_F32
 
 
-def gemm_tn_f32_supported(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor) -> bool:
-    return (X.dtype == torch.float32 and Y.dtype == torch.float32 and out.dtype == torch.float32 and X.dim() == 2 and Y.dim() == 2
+def gemm_tn_f32_supported(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor, f32_split: int = 0) -> bool:
+    """(the TN kernel exists in the split-bf16 forms only: under the exact arithmetic — VM_F32_SPLIT=0, gemm_f32_mode(0), f32_split=1 —
+    the caller takes the transpose + NT GEMM route)"""
+    return (f32_mode_resolved(f32_split) in (2, 3) and X.dtype == torch.float32 and Y.dtype == torch.float32 and out.dtype == torch.float32 and X.dim() == 2 and Y.dim() == 2
             and X.shape[0] == Y.shape[0] and X.stride(1) == 1 and Y.stride(1) == 1 and out.stride(1) == 1
             and X.shape[1] % 8 == 0 and Y.shape[1] % 8 == 0 and X.stride(0) % 4 == 0 and Y.stride(0) % 4 == 0
             and out.shape == (X.shape[1], Y.shape[1]))
@@ -318,7 +339,7 @@ def gemm_tn_f32_supported(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor) -
 def gemm_tn_f32(X: torch.Tensor, Y: torch.Tensor, out: torch.Tensor, *, colsum_out: torch.Tensor | None = None, f32_split: int = 0):
     """out[P, Q] += X[M, P]^T @ Y[M, Q] (fp32 operands as stored: the weight gradient dy^T x without transposed copies; split-bf16
     products, f32_split 2 / 3 / 0 = default); `colsum_out` fp32 [P] += column sums of X (the bias gradient)"""
-    assert gemm_tn_f32_supported(X, Y, out)
+    assert gemm_tn_f32_supported(X, Y, out, f32_split)
     M, P = X.shape
     Q = Y.shape[1]
     if colsum_out is not None:

@@ -63,6 +63,7 @@ class FlatAdamW:
                  max_grad_norm: float | None = None):
         self.ddp, self.lr, self.betas, self.eps, self.weight_decay = ddp, lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
+        ddp.defer_average = True          # finish() leaves the SUM over ranks; step() folds 1/world into the coefficient below
         self.step_count = 0
         self.last_lr = None
         self.flat_params, self.exp_avg, self.exp_avg_sq = [], [], []
@@ -89,8 +90,9 @@ class FlatAdamW:
         for b in self.ddp.buckets:
             v = torch.linalg.vector_norm(b.buffer, 2, dtype=torch.float32)
             sq = v * v if sq is None else sq + v * v
-        total = sq.sqrt()
-        coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0).reshape(1) if self.max_grad_norm is not None else None
+        gs = float(self.ddp.grad_scale)               # 1/world pending from a deferred finish(): the buckets hold the SUM
+        total = sq.sqrt() * gs                          # norm of the averaged gradient
+        coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0).reshape(1) * gs if self.max_grad_norm is not None else None
         return total, coef
 
     @torch.no_grad()
@@ -99,6 +101,9 @@ class FlatAdamW:
         lr = self.last_lr = self.current_lr()
         self.step_count += 1
         total, coef = self.grad_norm_and_coef() if self.max_grad_norm is not None else (None, None)
+        if coef is None and self.ddp.grad_scale != 1.0:
+            coef = torch.full((1,), float(self.ddp.grad_scale), dtype=torch.float32, device=self.ddp.buckets[0].buffer.device)
+        self.ddp.grad_scale = 1.0          # consumed: vm_adamw multiplies every gradient by coef as it reads it
         for b, p, m, v in zip(self.ddp.buckets, self.flat_params, self.exp_avg, self.exp_avg_sq):
             K.adamw_(p, b.buffer, m, v, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay if b.decay else 0.0,
                      step=self.step_count, clip_coef=coef)

@@ -160,3 +160,69 @@ def test_single_rank_rccl_path_equals_the_collective_free_path_bit_for_bit(dev):
     assert plain.keys() == rccl.keys() and len(plain) > 20
     for n in plain:
         assert (plain[n] == rccl[n]).all(), n
+
+
+def test_structural_production_order_matches_what_backward_does_on_the_real_model(dev):
+    """`ddp.production_stages` claims an order (heads, lm_head, norm, decoder L-1..0, embed_tokens, GLU adapter, ViT L-1..0, patch embedding);
+    the REAL tiny model (LM + ViT + LoRA + SAM / iSAM unfrozen, full training_step) records the order in which autograd finished the
+    slots. No bucket may wait for a LATER stage's gradients (then its all-reduce would not overlap with that stage's backward), and
+    only the tail buckets may be issued after the last gradient."""
+    from mmmm_amd.data.synthetic import SpecialTokens, make_batch
+    from mmmm_amd.ddp import BucketedGradAllReduce, grad_production_order, production_stages
+    from mmmm_amd.models.loss import DiceFocalLoss
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, MyPrecision, VisionArgs
+    from mmmm_amd.models.segvol.modeling.sam import InstanceSamLoss
+    from mmmm_amd.utils import apply_lora
+    from tests._gpu_common import randomize_
+    from tests.test_model_gpu import tiny_config
+    from tests.test_sam_gpu import _tiny_sams
+    sam, isam = _tiny_sams('cpu')
+    tok = SpecialTokens(base_vocab=184)
+    m = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(2, 2, 4), patch_size=(4, 8, 8)), tokenizer=tok,
+                              sam=sam, isam=isam, mask_loss=DiceFocalLoss(dice_weight=2, focal_weight=2, focal_gamma=2),
+                              isam_loss=InstanceSamLoss(use_neg_mask=False, box_l1_weight=5, box_giou_weight=2, disc_weight=2,
+                                                        disc_focal_gamma=2, disc_focal_alpha=0.85), config=tiny_config(),
+                              freeze_sam=False, freeze_isam=False)
+    apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    randomize_(m, 80)
+    m.to(dev)
+    MyPrecision().convert_module(m)
+    m.train()
+    m.sam.eval(); m.isam_model.eval()
+    m.on_fit_start()
+    names = {id(p): n for n, p in m.named_parameters()}
+    stages = production_stages(m)
+    stage = {id(p): i for i, st in enumerate(stages) for p in st}
+    seq = grad_production_order(m)
+    assert len(seq) == sum(p.requires_grad for p in m.parameters()) and len(stages) >= 8
+    ddp = BucketedGradAllReduce(seq, world_size=1, order='given', bucket_bytes=96 << 10, tail_bytes=32 << 10)
+    try:
+        assert len(ddp.buckets) >= 10
+        batch = make_batch([(3, 1, 16, 32), (3, 8, 16, 32), (3, 4, 32, 16)], [(1, 8, 8), (4, 8, 8), (2, 8, 8)], [(1, 2, 2), (2, 2, 2), (1, 1, 1)],
+                           [30, 28, 33], tok=tok, seed=8, instance=[False, True, False], device=dev, n_pairs=3)
+        ddp.zero_grad()
+        m.training_step(batch).backward()
+        ddp.finish()
+        torch.cuda.synchronize()
+        pos = {pid: i for i, pid in enumerate(ddp.ready_log)}
+        assert len(pos) == len(seq), 'a trainable parameter never reported ready'
+        # stage order as backward really produced it (first readiness of each stage must be non-decreasing in the claimed order)
+        first = [min(pos[id(p)] for p in st) for st in stages if st]
+        assert first == sorted(first), [(i, f) for i, f in enumerate(first)]
+        late = []
+        for (bi, at, by_finish), nxt in zip(ddp.launch_log, ddp.launch_log[1:]):
+            last_group = max(stage[id(p)] for p in ddp.buckets[bi].params)
+            later = [pos[id(p)] for p in ddp.buckets[nxt[0]].params if stage[id(p)] > last_group]
+            if later and (by_finish or at > min(later) + 1):
+                late.append((bi, names[id(ddp.buckets[bi].params[-1])]))
+        assert not late, late
+        rep = ddp.exposed_report()
+        # issued after the last gradient: at most the tail bucket of each (dtype, decay) stream that ends with the step
+        assert rep['exposed_bytes'] <= 4 * (32 << 10) + (96 << 10), rep['exposed_bytes']
+        print(f"[bucket order] {len(ddp.buckets)} buckets, {rep['exposed_bytes']} of {rep['total_bytes']} bytes issued after the last gradient, "
+              f"{rep['inversions']} buckets waited behind an earlier-indexed one")
+    finally:
+        ddp.remove()
+        for p in m.parameters():
+            p.grad = None

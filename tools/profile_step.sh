@@ -1,11 +1,11 @@
 #!/bin/bash
 # kernel trace + stats of a few steps of bench.py on the GPU box; writes gpurun_out/<tag>_timeline.md and <tag>_kernel_stats.md
-# usage (via gpurun): bash tools/profile_step.sh <tag> [bench.py arguments]
+# usage (via gpurun): bash tools/profile_step.sh <tag> [bench.py arguments]   (--also '' always: child benchmarks would inherit the profiler)
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o vm -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events "$@" > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o vm -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --also '' "$@" > /tmp/prof_$TAG.log 2>&1
 grep '^{' /tmp/prof_$TAG.log | cut -c1-260
 cd $R
 TRACE=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
