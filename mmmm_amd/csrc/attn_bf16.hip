@@ -10,6 +10,8 @@
 // ds_read_b64_tr_b16 from the row-major V tile. O^T keeps the query on the lane too, so rescaling by the running max is a
 // per-lane scalar. A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV): ~110 VGPRs, 16 waves per CU.
 // The backward is delta + two kernels of the same shape (dQ: query-stationary; dK/dV: key-stationary), no atomics.
+#include <mutex>
+#include <type_traits>
 #include "vm_common.hpp"
 #include "vm_tile.hpp"
 
@@ -39,7 +41,8 @@ struct AttnP {
   float* lse;
   const int32_t* cu; const int32_t* row_of_pos;
   int total_pos_max, n_heads;
-  int n_seq, n_tiles;      // 16-wide kernels: sequences, 128-position tiles per sequence (1-D XCD-aware grid)
+  int n_seq, n_tiles;      // sequences, workgroup tiles per sequence (1-D XCD-aware grid)
+  int q_block;             // 32-wide kernels: positions per workgroup tile (a multiple of 32: the sequence split evenly)
   float scale; int causal;
   const unsigned short* dout; int64_t lddo;
   unsigned short* dq; unsigned short* dk; unsigned short* dv; int64_t lddq, lddk, lddv;
@@ -193,6 +196,10 @@ __device__ __forceinline__ bool a16_block(const AttnP& p, int& tile, int& head, 
   seq = hs / p.n_heads;
   return true;
 }
+
+}  // namespace
+#include "attn32_fwd.hpp"
+namespace {
 
 // ----------------------------------------------------------------------------- forward (16 queries per wave)
 // STG (stagger): the second half of the workgroup's waves (one of every two waves that share a SIMD: guide 'Two waves per SIMD',
@@ -658,6 +665,52 @@ double attn_flops(const vm_attn_args* a, double mult) {
   return a->causal ? 0.5 * f : f;
 }
 
+
+// ---- forward launch. variant: 8 / 4 = the 32-query kernel with 8 / 4 waves per workgroup
+template <int HD, int NW>
+int fwd_launch32(const vm_attn_args* a, hipStream_t st) {
+  AttnP p = to_params(a);
+  p.n_tiles = (a->max_seqlen + NW * 32 - 1) / (NW * 32);
+  p.q_block = ((a->max_seqlen + p.n_tiles - 1) / p.n_tiles + 31) / 32 * 32;      // the sequence split evenly, in multiples of 32
+  constexpr int LDS = a32::fwd_lds<NW>();
+  const int pairs8 = (a->n_heads * a->n_seq + 7) / 8 * 8;
+  const dim3 grid((unsigned)(pairs8 * p.n_tiles)), block(NW * 64);
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    ok = lds_ok((const void*)a32::fwd_k<HD, NW, false>, LDS) && lds_ok((const void*)a32::fwd_k<HD, NW, true>, LDS);
+  });
+  if (!ok) return VM_ERR_LAUNCH;
+  if (a->causal) hipLaunchKernelGGL((a32::fwd_k<HD, NW, true>), grid, block, LDS, st, p);
+  else hipLaunchKernelGGL((a32::fwd_k<HD, NW, false>), grid, block, LDS, st, p);
+  return VM_OK;
+}
+
+int fwd_default_variant(const vm_attn_args* a) { return 8; }
+
+// (development A/B only, removed with the 16-wide forward: variant 16 = round 3's kernel)
+int fwd_launch16(const vm_attn_args* a, hipStream_t st) {
+  AttnP p = to_params(a);
+  p.n_tiles = (a->max_seqlen + 127) / 128;
+  switch (a->head_dim) {
+#define VM_A16_CASE(hd) case hd: if (!lds_ok((const void*)attn16_fwd_k<hd, 8, false>, A16_LDS_FWD)) return VM_ERR_LAUNCH; \
+    hipLaunchKernelGGL((attn16_fwd_k<hd, 8, false>), grid16(a, 128), dim3(512), A16_LDS_FWD, st, p); return VM_OK;
+    VM_A16_CASE(128) VM_A16_CASE(112)
+#undef VM_A16_CASE
+    default: return VM_ERR_UNSUPPORTED;
+  }
+}
+
+int fwd_launch(const vm_attn_args* a, hipStream_t st, int variant) {
+  if (variant == 16) return fwd_launch16(a, st);
+  switch (a->head_dim) {
+#define VM_A32_CASE(hd) case hd: return variant == 4 ? fwd_launch32<hd, 4>(a, st) : fwd_launch32<hd, 8>(a, st);
+    VM_A32_CASE(128) VM_A32_CASE(112) VM_A32_CASE(96) VM_A32_CASE(64) VM_A32_CASE(32) VM_A32_CASE(16)
+#undef VM_A32_CASE
+    default: return VM_ERR_UNSUPPORTED;
+  }
+}
+
 }  // namespace
 
 #define ATTN_DISPATCH_HD(hd, ...)                         \
@@ -676,19 +729,11 @@ extern "C" {
 int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   if (!args_ok(a)) return VM_ERR_BAD_ARG;
   if (!fits32(a)) return VM_ERR_UNSUPPORTED;
-  AttnP p = to_params(a);
-  dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  const int nw = attn_nw(a);
-  p.n_tiles = (a->max_seqlen + nw * 16 - 1) / (nw * 16);
-    ATTN_DISPATCH_HD(a->head_dim,
-                     if (!lds_ok((const void*)attn16_fwd_k<HD, 8, true>, A16_LDS_FWD) || !lds_ok((const void*)attn16_fwd_k<HD, 16, true>, A16_LDS_FWD) ||
-                         !lds_ok((const void*)attn16_fwd_k<HD, 8, false>, A16_LDS_FWD)) return VM_ERR_LAUNCH;
-                     if (nw == 16) hipLaunchKernelGGL((attn16_fwd_k<HD, 16, true>), grid16(a, 256), dim3(1024), A16_LDS_FWD, (hipStream_t)stream, p);
-                     else if (attn_stagger()) hipLaunchKernelGGL((attn16_fwd_k<HD, 8, true>), grid16(a, 128), dim3(512), A16_LDS_FWD, (hipStream_t)stream, p);
-                     else hipLaunchKernelGGL((attn16_fwd_k<HD, 8, false>), grid16(a, 128), dim3(512), A16_LDS_FWD, (hipStream_t)stream, p));
+  const int rc = fwd_launch(a, (hipStream_t)stream, fwd_default_variant(a));
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
+  if (rc != VM_OK) return rc;
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

@@ -218,8 +218,11 @@ def test_structural_production_order_matches_what_backward_does_on_the_real_mode
                 late.append((bi, names[id(ddp.buckets[bi].params[-1])]))
         assert not late, late
         rep = ddp.exposed_report()
-        # issued after the last gradient: at most the tail bucket of each (dtype, decay) stream that ends with the step
-        assert rep['exposed_bytes'] <= 4 * (32 << 10) + (96 << 10), rep['exposed_bytes']
+        # issued after the last gradient: at most the tail bucket of each (dtype, decay) stream that ends with the step — a tail holds
+        # up to tail_bytes, or ONE parameter larger than that (the patch-embedding kernel, the position table)
+        biggest = max(p.numel() * p.element_size() for p in seq)
+        assert rep['exposed_bytes'] <= 4 * (32 << 10) + 2 * biggest, (rep['exposed_bytes'], biggest)
+        assert rep['exposed_bytes'] <= 0.2 * rep['total_bytes'], (rep['exposed_bytes'], rep['total_bytes'])
         print(f"[bucket order] {len(ddp.buckets)} buckets, {rep['exposed_bytes']} of {rep['total_bytes']} bytes issued after the last gradient, "
               f"{rep['inversions']} buckets waited behind an earlier-indexed one")
     finally:

@@ -1,0 +1,148 @@
+// Stand-alone A/B bench + check of the bf16 attention kernels (no torch): includes the library's translation unit, so the
+// kernels timed here are the ones that ship. Variants are interleaved in ONE process (guide rule 24), random data (rule 25).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVM_KEEP_DENORMS tools/ubench/attn_bench.hip -o tools/ubench/attn_bench
+//   tools/ubench/attn_bench [rounds]
+#include "../../mmmm_amd/csrc/attn_bf16.hip"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" int vm_prof_begin_(int, void*, void**) { return 0; }
+extern "C" int vm_prof_end_(int, void*, void*, double) { return 0; }
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+// reference: one workgroup per (position, head), fp32
+__global__ void ref_fwd_k(const unsigned short* q, const unsigned short* k, const unsigned short* v, int64_t ld, const int* cu, int n_seq, int H, int hd,
+                          float scale, int causal, float* out, float* lse, int total) {
+  const int gpos = blockIdx.x, head = blockIdx.y;
+  int seq = 0;
+  while (seq + 1 < n_seq && cu[seq + 1] <= gpos) ++seq;
+  const int s0 = cu[seq], L = cu[seq + 1] - s0, qp = gpos - s0;
+  const int lim = causal ? qp : L - 1;
+  __shared__ float sc[8192];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float mx = -1e30f;
+  for (int j = tid; j <= lim; j += blockDim.x) {
+    float a = 0.f;
+    for (int d = 0; d < hd; ++d) a += bf2f(q[(int64_t)gpos * ld + head * hd + d]) * bf2f(k[(int64_t)(s0 + j) * ld + head * hd + d]);
+    a *= scale;
+    sc[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  red[tid] = mx; __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  mx = red[0]; __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j <= lim; j += blockDim.x) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+  red[tid] = sum; __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  sum = red[0]; __syncthreads();
+  for (int d = tid; d < hd; d += blockDim.x) {
+    float a = 0.f;
+    for (int j = 0; j <= lim; ++j) a += sc[j] * bf2f(v[(int64_t)(s0 + j) * ld + head * hd + d]);
+    out[(int64_t)gpos * H * hd + head * hd + d] = a / sum;
+  }
+  if (tid == 0) lse[(int64_t)head * total + gpos] = mx + logf(sum);
+}
+
+struct Shape { const char* name; std::vector<int> lens; int H, hd, causal; };
+
+static unsigned short f2bf_host(float f) { unsigned u; std::memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static float bf2f_host(unsigned short b) { unsigned u = (unsigned)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static float gauss() { float a = (float)((rand() + 1.0) / (RAND_MAX + 2.0)), b = (float)((rand() + 1.0) / (RAND_MAX + 2.0)); return sqrtf(-2.f * logf(a)) * cosf(6.2831853f * b); }
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 10;
+  std::vector<Shape> shapes = {
+    {"vit-e 8x785 h16 d112", std::vector<int>(8, 785), 16, 112, 0},
+    {"decoder 8x456 h32 d128 causal", std::vector<int>(8, 456), 32, 128, 1},
+    {"3d 4x4609 h16 d112", std::vector<int>(4, 4609), 16, 112, 0},
+    {"grg 8x2049 h16 d112", std::vector<int>(8, 2049), 16, 112, 0},
+    {"ragged h2 d128 causal", {130, 64, 1, 200, 456}, 2, 128, 1},
+    {"ragged h3 d64", {33, 785, 7}, 3, 64, 0},
+  };
+  const std::vector<int> variants = {16, 8, 4};
+  for (const Shape& sh : shapes) {
+    const int n_seq = (int)sh.lens.size();
+    std::vector<int> cu(n_seq + 1, 0);
+    int maxlen = 0;
+    for (int i = 0; i < n_seq; ++i) { cu[i + 1] = cu[i] + sh.lens[i]; maxlen = std::max(maxlen, sh.lens[i]); }
+    const int rows = cu[n_seq], H = sh.H, hd = sh.hd;
+    const int64_t ld = 3LL * H * hd;
+    std::vector<unsigned short> hq((size_t)rows * ld);
+    srand(1234);
+    for (auto& x : hq) x = f2bf_host(gauss());
+    unsigned short *dqkv, *dout;
+    float *dlse, *dref, *dlse_ref;
+    int* dcu;
+    CK(hipMalloc(&dqkv, hq.size() * 2)); CK(hipMalloc(&dout, (size_t)rows * H * hd * 2));
+    CK(hipMalloc(&dlse, (size_t)H * rows * 4)); CK(hipMalloc(&dref, (size_t)rows * H * hd * 4)); CK(hipMalloc(&dlse_ref, (size_t)H * rows * 4));
+    CK(hipMalloc(&dcu, (n_seq + 1) * 4));
+    CK(hipMemcpy(dqkv, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dcu, cu.data(), (n_seq + 1) * 4, hipMemcpyHostToDevice));
+    const float scale = 1.0f / sqrtf((float)hd);
+    const bool check = (double)rows * maxlen * H < 6e8;
+    if (check) {
+      hipLaunchKernelGGL(ref_fwd_k, dim3(rows, H), dim3(128), 0, 0, dqkv, dqkv + H * hd, dqkv + 2 * H * hd, ld, dcu, n_seq, H, hd, scale, sh.causal, dref, dlse_ref, rows);
+      CK(hipDeviceSynchronize());
+    }
+    vm_attn_args a = {};
+    a.q = dqkv; a.k = dqkv + H * hd; a.v = dqkv + 2 * H * hd; a.out = dout;
+    a.ldq = a.ldk = a.ldv = ld; a.ldo = H * hd;
+    a.lse = dlse; a.cu_seqlens = dcu; a.n_seq = n_seq; a.row_of_pos = nullptr;
+    a.total_pos_max = rows; a.max_seqlen = maxlen; a.n_heads = H; a.head_dim = hd; a.scale = scale; a.causal = sh.causal;
+    double flops = 0;
+    for (int l : sh.lens) flops += 4.0 * l * l * hd * H * (sh.causal ? 0.5 : 1.0);
+    printf("== %s  (%.2f GFLOP)\n", sh.name, flops / 1e9);
+    std::vector<std::vector<float>> times(variants.size());
+    std::vector<bool> ok(variants.size(), true);
+    std::vector<float> href, hlse_ref;
+    if (check) { href.resize((size_t)rows * H * hd); hlse_ref.resize((size_t)H * rows);
+      CK(hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hlse_ref.data(), dlse_ref, hlse_ref.size() * 4, hipMemcpyDeviceToHost)); }
+    for (size_t vi = 0; vi < variants.size(); ++vi) {
+      CK(hipMemset(dout, 0xFF, (size_t)rows * H * hd * 2));
+      const int rc = fwd_launch(&a, 0, variants[vi]);
+      if (rc != VM_OK) { ok[vi] = false; printf("  variant %2d: unsupported (rc %d)\n", variants[vi], rc); continue; }
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) { printf("  variant %2d: launch failed: %s\n", variants[vi], hipGetErrorString(e)); return 1; }
+      if (check) {
+        std::vector<unsigned short> ho((size_t)rows * H * hd);
+        std::vector<float> hl((size_t)H * rows);
+        CK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hl.data(), dlse, hl.size() * 4, hipMemcpyDeviceToHost));
+        double num = 0, den = 0, mx = 0, lmx = 0;
+        for (size_t i = 0; i < ho.size(); ++i) { const double d = bf2f_host(ho[i]) - href[i]; num += d * d; den += (double)href[i] * href[i]; mx = std::max(mx, std::fabs(d)); }
+        for (size_t i = 0; i < hl.size(); ++i) lmx = std::max(lmx, (double)std::fabs(hl[i] - hlse_ref[i]));
+        printf("  variant %2d: rel L2 err %.2e  max abs %.2e  lse max abs %.2e %s\n", variants[vi], std::sqrt(num / den), mx, lmx,
+               (std::sqrt(num / den) < 6e-3 && lmx < 2e-3) ? "OK" : "**** MISMATCH ****");
+      }
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int r = 0; r < rounds; ++r)
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        if (!ok[vi]) continue;
+        const int reps = 5;
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) fwd_launch(&a, 0, variants[vi]);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) times[vi].push_back(ms / reps * 1e3f);
+      }
+    for (size_t vi = 0; vi < variants.size(); ++vi) {
+      if (!ok[vi] || times[vi].empty()) continue;
+      std::sort(times[vi].begin(), times[vi].end());
+      const float med = times[vi][times[vi].size() / 2], mn = times[vi][0];
+      printf("  variant %2d: fwd median %7.1f us (min %7.1f)  %6.0f TFLOP/s\n", variants[vi], med, mn, flops / (med * 1e-6) / 1e12);
+    }
+    CK(hipFree(dqkv)); CK(hipFree(dout)); CK(hipFree(dlse)); CK(hipFree(dref)); CK(hipFree(dlse_ref)); CK(hipFree(dcu));
+  }
+  return 0;
+}
