@@ -3,15 +3,15 @@
 //   modeling_cogvlm.py:113-128  BlockDiagonalCausalMask, head_dim 128 (LM)
 //   visual.py:91-99             BlockDiagonalMask, head_dim 112 (EVA ViT)
 //
-// Layout (guide §3 "An accumulator tile as the next MFMA's operand"): scores are computed TRANSPOSED,
-// S^T[kv][q] = K·Q^T with v_mfma_f32_16x16x32_bf16, so that the query index sits on the lane (col = lane & 15) and a
-// lane's registers are kv positions. Row max / sum are in-lane reductions plus two shuffles, and two stacked accumulator
-// tiles, converted to bf16, are directly the B operand of O^T[d][q] += V^T·P^T whose A operand (V^T) is fetched with
-// ds_read_b64_tr_b16 from the row-major V tile. O^T keeps the query on the lane too, so rescaling by the running max is a
-// per-lane scalar. A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV): ~110 VGPRs, 16 waves per CU.
-// The backward is delta + two kernels of the same shape (dQ: query-stationary; dK/dV: key-stationary), no atomics.
+// FORWARD: attn32_fwd.hpp — 8 waves x 32 queries on v_mfma_f32_32x32x16_bf16, four barrier-separated clusters per 64-key tile with
+// the two waves of every SIMD one cluster apart (guide T16); its header has the structure and the measurements behind it.
+// BACKWARD (this file): delta + two kernels, no atomics — dQ is query-stationary, dK/dV key-stationary; a wave owns 16 queries / keys
+// on v_mfma_f32_16x16x32_bf16 (~110-164 VGPRs). Scores are computed TRANSPOSED (guide §3 "An accumulator tile as the next MFMA's
+// operand"), S^T[kv][q] = K Q^T, so the query index sits on the lane and two stacked accumulator tiles, converted to bf16, are
+// directly the B operand of the next product; the transposed operands come from the row-major tiles through ds_read_b64_tr_b16.
 #include <mutex>
 #include <type_traits>
+#include <utility>
 #include "vm_common.hpp"
 #include "vm_tile.hpp"
 
@@ -47,6 +47,7 @@ struct AttnP {
   const unsigned short* dout; int64_t lddo;
   unsigned short* dq; unsigned short* dk; unsigned short* dv; int64_t lddq, lddk, lddv;
   float* delta;
+  unsigned long long* dbg;   // diagnostic builds only (-DA32_STAMPS)
 };
 
 __device__ __forceinline__ int phys_row(const AttnP& p, int gpos) {
@@ -200,167 +201,6 @@ __device__ __forceinline__ bool a16_block(const AttnP& p, int& tile, int& head, 
 }  // namespace
 #include "attn32_fwd.hpp"
 namespace {
-
-// ----------------------------------------------------------------------------- forward (16 queries per wave)
-// STG (stagger): the second half of the workgroup's waves (one of every two waves that share a SIMD: guide 'Two waves per SIMD',
-// item 9: split by wave number, not parity) defers the P V product of a tile to the NEXT iteration. Every wave runs
-// S = K Q^T (MFMA) -> softmax (VALU) -> O += V^T P^T (MFMA) and the one barrier per tile keeps all waves in step, so without the
-// stagger the SIMD's waves fight for the matrix pipe in two of the three phases and for the VALU in the third (PMC, round 3:
-// MFMA busy 0.24, parked at s_waitcnt / barrier 0.43 of the wave cycles). With it the late half runs [P V of tile t-1, S of t, softmax]
-// against the early half's [S, softmax, P V]: the early half's softmax meets the late half's S product, the early half's P V the late
-// half's softmax. V tiles then live one iteration longer: K ring of 2, V ring of 3 (80 KiB, two 8-wave workgroups per CU).
-constexpr int A16_TILE = 64 * ROWB;
-constexpr int A16_LDS_FWD = 5 * A16_TILE;           // K[2] | V[3]
-
-template <int HD, int NW, bool STG>
-__global__ __launch_bounds__(NW * 64, 4) void attn16_fwd_k(const AttnP p) {
-  constexpr int QB = NW * 16;            // positions per workgroup
-  constexpr int KS = (HD + 31) / 32;
-  constexpr int ND = HD / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ln = lane & 15, g = lane >> 4;
-  int tile_, head, seq;
-  if (!a16_block(p, tile_, head, seq)) return;
-  const int seq0 = p.cu[seq];
-  const int seqlen = p.cu[seq + 1] - seq0;
-  const int q0 = tile_ * QB;
-  if (q0 >= seqlen) return;
-  const int qpos = q0 + wave * 16 + ln;
-  const bool qvalid = qpos < seqlen;
-  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
-  const bool late = STG && wave >= NW / 2;
-
-  bf16x8_t qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    i32x4_t v = {0, 0, 0, 0};
-    if (qvalid && 32 * s + 8 * g < HD) v = *reinterpret_cast<const i32x4_t*>(p.q + qrow * p.ldq + head * HD + 32 * s + 8 * g);
-    qf[s] = __builtin_bit_cast(bf16x8_t, v);
-  }
-  f32x4_t o[ND];
-#pragma unroll
-  for (int b = 0; b < ND; ++b) o[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = NEG_BIG, l_run = 0.f;
-  const float sc = p.scale * LOG2E;
-
-  const int kv_end = p.causal ? min(seqlen, q0 + QB) : seqlen;
-  const int nt = (kv_end + 63) / 64;
-  const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k), rV = whole_rsrc(p.v);
-  const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
-  char* kring = smem;                       // tile t in slot t & 1
-  char* vring = smem + 2 * A16_TILE;        // tile t in slot t % 3
-  StageLane sl;
-  sl.init<HD, NW>(head, wave, lane);
-  int pr[2];
-  a16_rows<NW>(p, seq0, seqlen, 0, wave, lane, pr);
-  a16_stage<NW>(rK, ldk_b, sl, seqlen - (0), pr, kring, wave);
-  a16_stage<NW>(rV, ldv_b, sl, seqlen - (0), pr, vring, wave);
-  if (nt > 1) a16_rows<NW>(p, seq0, seqlen, 64, wave, lane, pr);
-  A16_WAIT_ALL();
-  __syncthreads();
-
-  bf16x8_t pprev[2];                        // late waves: P of the previous tile, waiting for its P V
-  auto pv = [&](const char* sV, const bf16x8_t (&pf)[2]) {      // O^T[d][q] += V^T · P^T
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int b = 0; b < ND; ++b)
-        o[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sV, 32 * c, b, lane), pf[c], o[b], 0, 0, 0);
-  };
-  int vs = 0;                               // V ring slot of tile t (t % 3 without a division)
-  for (int t = 0; t < nt; ++t) {
-    const int vs_next = vs == 2 ? 0 : vs + 1;
-    if (t + 1 < nt) {
-      a16_stage<NW>(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, kring + ((t + 1) & 1) * A16_TILE, wave);
-      a16_stage<NW>(rV, ldv_b, sl, seqlen - ((t + 1) * 64), pr, vring + vs_next * A16_TILE, wave);
-      if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
-    }
-    const char* sK = kring + (t & 1) * A16_TILE;
-    const char* sV = vring + vs * A16_TILE;
-    if (late && t > 0) pv(vring + (vs == 0 ? 2 : vs - 1) * A16_TILE, pprev);      // the deferred product of tile t - 1
-    const int kv0 = t * 64;
-    // S^T sub-tiles: sacc[j][r] = score(kv = kv0 + 16 j + 4 g + r, q = this lane's query)
-    f32x4_t sacc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, 0, lane), qf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-      for (int s = 1; s < KS; ++s)
-        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sacc[j], 0, 0, 0);
-    }
-    // masking only on tiles that touch the sequence end or the causal diagonal (wave-uniform test)
-    if (kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16)) {
-      const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[j][r] = (kv0 + 16 * j + 4 * g + r <= lim) ? sacc[j][r] : NEG_BIG;
-    }
-    float mx = NEG_BIG;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[j][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float msc = m_new * sc;
-    const float alpha = fast_exp2(m_run * sc - msc);
-    float rs = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = fast_exp2(__builtin_fmaf(sacc[j][r], sc, -msc));
-        sacc[j][r] = e;
-        rs += e;
-      }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int b = 0; b < ND; ++b) o[b] *= alpha;            // (a wave-uniform "max unchanged" branch costs more in copies)
-    const bf16x8_t pf[2] = {pack2(sacc[0], sacc[1]), pack2(sacc[2], sacc[3])};
-    if (late) { pprev[0] = pf[0]; pprev[1] = pf[1]; }
-    else pv(sV, pf);
-    vs = vs_next;
-    A16_WAIT_ALL();
-    __syncthreads();
-  }
-  if (late && nt > 0) pv(vring + (vs == 0 ? 2 : vs - 1) * A16_TILE, pprev);        // (no DMA is in flight any more: the last V tile is intact)
-
-  if (!qvalid) return;
-  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
-  if (g == 0 && p.lse) p.lse[(int64_t)head * p.total_pos_max + seq0 + qpos] = (m_run * sc + log2f(l_run)) * LN2;
-  unsigned short* orow = p.out + qrow * p.ldo + head * HD;
-#pragma unroll
-  for (int b = 0; b < ND; ++b) {
-    const u16x4_t w = {f2bf(o[b][0] * inv_l), f2bf(o[b][1] * inv_l), f2bf(o[b][2] * inv_l), f2bf(o[b][3] * inv_l)};
-    *reinterpret_cast<u16x4_t*>(orow + 16 * b + 4 * g) = w;
-  }
-}
-
-// Measured [r3], built and removed: the forward software-pipelined inside each wave (scores of tile t + 1 issued under the softmax of
-// tile t, every K / V fragment read one or two MFMAs ahead of its use, the order pinned by scheduling fences; K consumed one tile
-// ahead of V on the same four LDS tiles; bit-identical, 58 attention tests green): ViT-E 85-86 vs 82-83 us, decoder 66 vs 49 us.
-// A wave's own latencies are not what bounds the kernel — four waves per SIMD already cover them. Per round of 256 queries x 64
-// keys and CU the three pipes cost: LDS 16 waves x (16 K-fragment reads of 1 KiB + 28 transposed V reads of 512 B) = 480 KiB at
-// 128 B/clk = 3 840 cycles; VALU 4 waves x ~800 = 3 200 cycles per SIMD; matrix pipe 4 x 480 = 1 920. Measured ~7 900 cycles per
-// round: the three barely overlap (the barrier per tile puts a workgroup's waves into the same phase), and the largest is the LDS
-// read stream, which re-reads each K / V tile once per 16 queries. Halving it needs 32 queries per wave (two B operands per K
-// fragment: ~200 VGPRs, two waves per SIMD) — a different kernel.
-// ... which was then built too (attn32_fwd_k: 4 waves x 2 groups of 16 queries, every K / V fragment feeding two MFMAs, 215-233 VGPRs,
-// two 4-wave workgroups per CU; bit-identical): ViT-E 79-84 vs 81-83 us, decoder 47-49 vs 46-49 us. So it is not the LDS stream
-// either. What the forward's 82 us consist of was then measured by knocking parts out (debug builds, tools/ubench notes in DESIGN
-// section 3): no K / V DMA 68 us, no softmax 65, no P V product 64, no barrier 73, no DMA and no softmax 53 — the parts ADD UP
-// (DMA 14 + softmax 17 + P V 18 + scores ~18 + barrier 9 + fixed ~8), nothing hides behind anything else, although the softmax is
-// VALU work and the products matrix work of (in the 4-wave form) unsynchronised waves on the same SIMD. Inside the softmax neither the
-// 17 quarter-rate exponentials (replaced by a multiply: 80 us) nor the four ds_bpermute round trips (replaced by
-// v_permlane16/32_swap: 82-84 us) matter; it is the ~100 plain VALU instructions per tile (a third of them moves and LDS address
-// arithmetic). The lever that is left is instruction count: tiles unrolled by two so that ring addresses are immediates, no copies.
 
 // ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
 template <int HD, int NW>
@@ -616,6 +456,7 @@ AttnP to_params(const vm_attn_args* a) {
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv;
   p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
   p.delta = a->delta;
+  p.dbg = nullptr;
   return p;
 }
 
@@ -650,14 +491,6 @@ int attn_nw(const vm_attn_args* a) {
   static const int forced = [] { const char* e = getenv("VM_ATTN_NW"); return e ? atoi(e) : 8; }();
   return (forced == 16 && a->max_seqlen > 192) ? 16 : 8;
 }
-// Measured [r3]: the staggered forward is SLOWER — ViT-E [8 x 785, 16 heads of 112] 107 vs 82 us, decoder [8 x 456, 32 heads of 128,
-// causal] 85 vs 51 us (tools/bench_attn.py, one process each): the two orders of the loop body cost 12-28 VGPR spill slots under the
-// 128-register cap that four waves per SIMD impose. Off by default; VM_ATTN_STAGGER=1 for A/B runs.
-bool attn_stagger() {
-  static const int v = [] { const char* e = getenv("VM_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
-  return v != 0;
-}
-
 double attn_flops(const vm_attn_args* a, double mult) {
   // upper bound with every sequence at max_seqlen; bench uses equal-length sequences so it is exact
   const double L = a->max_seqlen;
@@ -666,45 +499,43 @@ double attn_flops(const vm_attn_args* a, double mult) {
 }
 
 
-// ---- forward launch. variant: 8 / 4 = the 32-query kernel with 8 / 4 waves per workgroup
-template <int HD, int NW>
+#ifdef A32_STAMPS
+unsigned long long* g_a32_dbg = nullptr;
+#endif
+// ---- forward launch
+template <int HD>
 int fwd_launch32(const vm_attn_args* a, hipStream_t st) {
+  constexpr int NW = a32::NW;
   AttnP p = to_params(a);
+#ifdef A32_STAMPS
+  p.dbg = g_a32_dbg;
+#endif
   p.n_tiles = (a->max_seqlen + NW * 32 - 1) / (NW * 32);
-  p.q_block = ((a->max_seqlen + p.n_tiles - 1) / p.n_tiles + 31) / 32 * 32;      // the sequence split evenly, in multiples of 32
-  constexpr int LDS = a32::fwd_lds<NW>();
+  // full 256-query workgroups and ONE short one per sequence (785 = 3 x 256 + 17) rather than an even split (4 x 224): the short
+  // workgroup's single live wave has its SIMD to itself and is done in about half the time, and the dispatcher hands its CU the
+  // next workgroup — 1.5 + 0.25 rounds of full workgroups instead of 2 on the 8 x 785 ViT-E shape
+  p.q_block = NW * 32;
+  // rings / epilogue slabs, plus the sequence's slice of row_of_pos when the layout is indirect
+  const int lds = a32::RING_LDS + (a->row_of_pos ? (a->max_seqlen + 3) / 4 * 16 : 0);
+  if (lds > 160 * 1024) return VM_ERR_UNSUPPORTED;
   const int pairs8 = (a->n_heads * a->n_seq + 7) / 8 * 8;
   const dim3 grid((unsigned)(pairs8 * p.n_tiles)), block(NW * 64);
   static std::once_flag once;
   static bool ok = false;
   std::call_once(once, [] {
-    ok = lds_ok((const void*)a32::fwd_k<HD, NW, false>, LDS) && lds_ok((const void*)a32::fwd_k<HD, NW, true>, LDS);
+    ok = lds_ok((const void*)a32::fwd_k<HD, false>, 160 * 1024) && lds_ok((const void*)a32::fwd_k<HD, true>, 160 * 1024);
   });
   if (!ok) return VM_ERR_LAUNCH;
-  if (a->causal) hipLaunchKernelGGL((a32::fwd_k<HD, NW, true>), grid, block, LDS, st, p);
-  else hipLaunchKernelGGL((a32::fwd_k<HD, NW, false>), grid, block, LDS, st, p);
+  if (a->causal) hipLaunchKernelGGL((a32::fwd_k<HD, true>), grid, block, lds, st, p);
+  else hipLaunchKernelGGL((a32::fwd_k<HD, false>), grid, block, lds, st, p);
   return VM_OK;
 }
 
 int fwd_default_variant(const vm_attn_args* a) { return 8; }
 
-// (development A/B only, removed with the 16-wide forward: variant 16 = round 3's kernel)
-int fwd_launch16(const vm_attn_args* a, hipStream_t st) {
-  AttnP p = to_params(a);
-  p.n_tiles = (a->max_seqlen + 127) / 128;
-  switch (a->head_dim) {
-#define VM_A16_CASE(hd) case hd: if (!lds_ok((const void*)attn16_fwd_k<hd, 8, false>, A16_LDS_FWD)) return VM_ERR_LAUNCH; \
-    hipLaunchKernelGGL((attn16_fwd_k<hd, 8, false>), grid16(a, 128), dim3(512), A16_LDS_FWD, st, p); return VM_OK;
-    VM_A16_CASE(128) VM_A16_CASE(112)
-#undef VM_A16_CASE
-    default: return VM_ERR_UNSUPPORTED;
-  }
-}
-
 int fwd_launch(const vm_attn_args* a, hipStream_t st, int variant) {
-  if (variant == 16) return fwd_launch16(a, st);
   switch (a->head_dim) {
-#define VM_A32_CASE(hd) case hd: return variant == 4 ? fwd_launch32<hd, 4>(a, st) : fwd_launch32<hd, 8>(a, st);
+#define VM_A32_CASE(hd) case hd: return fwd_launch32<hd>(a, st);
     VM_A32_CASE(128) VM_A32_CASE(112) VM_A32_CASE(96) VM_A32_CASE(64) VM_A32_CASE(32) VM_A32_CASE(16)
 #undef VM_A32_CASE
     default: return VM_ERR_UNSUPPORTED;

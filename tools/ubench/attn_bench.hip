@@ -59,6 +59,8 @@ static float gauss() { float a = (float)((rand() + 1.0) / (RAND_MAX + 2.0)), b =
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 10;
+  const int only_shape = argc > 2 ? atoi(argv[2]) : -1;          // run one shape / one variant (profiler passes)
+  const int only_variant = argc > 3 ? atoi(argv[3]) : -1;
   std::vector<Shape> shapes = {
     {"vit-e 8x785 h16 d112", std::vector<int>(8, 785), 16, 112, 0},
     {"decoder 8x456 h32 d128 causal", std::vector<int>(8, 456), 32, 128, 1},
@@ -67,8 +69,11 @@ int main(int argc, char** argv) {
     {"ragged h2 d128 causal", {130, 64, 1, 200, 456}, 2, 128, 1},
     {"ragged h3 d64", {33, 785, 7}, 3, 64, 0},
   };
-  const std::vector<int> variants = {16, 8, 4};
-  for (const Shape& sh : shapes) {
+  std::vector<int> variants = {8};
+  if (only_variant >= 0) variants = {only_variant};
+  for (size_t si = 0; si < shapes.size(); ++si) {
+    if (only_shape >= 0 && (int)si != only_shape) continue;
+    const Shape& sh = shapes[si];
     const int n_seq = (int)sh.lens.size();
     std::vector<int> cu(n_seq + 1, 0);
     int maxlen = 0;
@@ -136,6 +141,35 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0) times[vi].push_back(ms / reps * 1e3f);
       }
+#ifdef A32_STAMPS
+    {
+      const int nwv = only_variant == 4 ? 4 : 8;
+      const int nb = 8 * (((H * n_seq + 7) / 8) * ((maxlen + nwv * 32 - 1) / (nwv * 32)));
+      unsigned long long* dbg;
+      CK(hipMalloc(&dbg, (size_t)nb * 8 * 12 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 8 * 12 * 8));
+      g_a32_dbg = dbg;
+      fwd_launch(&a, 0, nwv);
+      CK(hipDeviceSynchronize());
+      g_a32_dbg = nullptr;
+      std::vector<unsigned long long> hd_((size_t)nb * 8 * 12);
+      CK(hipMemcpy(hd_.data(), dbg, hd_.size() * 8, hipMemcpyDeviceToHost));
+      double sum[2][12] = {}; double cnt[2] = {0, 0}, tiles[2] = {0, 0};
+      for (int b = 0; b < nb; ++b) for (int w = 0; w < nwv; ++w) {
+        const unsigned long long* d = &hd_[((size_t)b * nwv + w) * 12];
+        if (d[9] == 0) continue;
+        const int g = nwv == 8 && w >= 4;
+        for (int i = 0; i < 9; ++i) sum[g][i] += (double)d[i];
+        sum[g][10] += (double)d[10]; sum[g][11] += (double)d[11];
+        cnt[g] += 1; tiles[g] += (double)d[9];
+      }
+      for (int g = 0; g < 2; ++g) {
+        printf("  stamps %s waves (%d live, %.1f tiles each): per tile cycles", g ? "late " : "early", (int)cnt[g], tiles[g] / std::max(cnt[g], 1.0));
+        for (int i = 0; i < 4; ++i) printf("  c%d work %5.0f wait %5.0f", i, sum[g][2 * i] / tiles[g], sum[g][2 * i + 1] / tiles[g]);
+        printf("  | c2: reads done at %.0f, max + decision at %.0f | loop total %.0f per wave\n", sum[g][10] / tiles[g], sum[g][11] / tiles[g], sum[g][8] / cnt[g]);
+      }
+      CK(hipFree(dbg));
+    }
+#endif
     for (size_t vi = 0; vi < variants.size(); ++vi) {
       if (!ok[vi] || times[vi].empty()) continue;
       std::sort(times[vi].begin(), times[vi].end());
