@@ -142,103 +142,110 @@ def make_batch(workload: dict, tok, B: int, device, seed: int):
               seed=seed, grounding=workload['sam'], n_pairs=4, instance=inst, device=device)
 
 
-def cpu_baseline(workload: dict, cfg, seconds_budget: float = 30.0) -> dict:
-    """The CPU oracle (oracle/vividmed.py, pinned against the reference) timed on the host cores on a bounded sample:
-    ONE true-width decoder layer + ONE true-width ViT layer + lm_head/CE, forward+backward, for one image of the
-    workload; extrapolated linearly in depth (32 / 63 layers). Reported baseline, not a target."""
-    from oracle import vividmed as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    vc = cfg.vision_config
-    ocfg = O.Cfg(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=1,
-                 num_attention_heads=cfg.num_attention_heads,
-                 vision=O.VisionCfg(hidden_size=vc['hidden_size'], num_heads=vc['num_heads'], num_hidden_layers=1,
-                                    intermediate_size=vc['intermediate_size'], layer_norm_eps=vc['layer_norm_eps']))
-    img, patch, pool = workload['image'], workload['patch'], workload['pool']
-    grid = [img[1 + k] // patch[k] for k in range(3)]
-    Nv = math.prod(grid) + 1
-    Np = math.prod(g // p for g, p in zip(grid, pool))
-    L = 1 + (Np + 2) + 1 + workload['text']
-    h, i, d, f = cfg.hidden_size, cfg.intermediate_size, vc['hidden_size'], vc['intermediate_size']
+def _oracle_state_and_batch(workload: dict, cfg, n_dec: int, n_vit: int, tok):
+    """state dict of the REAL module tree at the true widths with `n_dec` decoder and `n_vit` ViT-E layers (built on the meta device,
+    materialised from one tiled 1 M-element normal sample: timing only), LoRA r64 applied, SAM-B + iSAM when the workload has them —
+    and ONE image of the workload as the reference's Batch on the CPU."""
+    import copy
+    from mmmm_amd.data.synthetic import make_batch as mk
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, VisionArgs
+    from mmmm_amd.utils import apply_lora
+    c = copy.deepcopy(cfg)
+    c.num_hidden_layers = n_dec
+    c.vision_config = dict(c.vision_config, num_hidden_layers=n_vit)
+    try:
+        with torch.device('meta'):
+            sam = isam = None
+            if workload['sam']:
+                from mmmm_amd.models.segvol import build_sam, build_instance_sam
+                sam = build_sam(patch_size=16, pos_embed_shape=(8, 32, 32))
+                isam = build_instance_sam(patch_size=16, num_instances=6, pos_embed_shape=(8, 32, 32))
+            m = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(8, 32, 32), pt_pos_embed_shape=(35, 35), patch_size=16),
+                                      tokenizer=tok, sam=sam, mask_loss=None, isam=isam, isam_loss=None, config=c, freeze_sam=False, freeze_isam=False)
+            apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    finally:
+        torch.set_default_dtype(torch.float32)
     g = torch.Generator().manual_seed(0)
     base = torch.randn(1 << 20, generator=g) * 0.02
-
-    _by_shape: dict = {}
-
-    def r(*s):       # timing only: a tiled 1M-element normal sample, one buffer per distinct shape (0.6 G normals through the
-        if s in _by_shape:       # scalar generator took 20 s of this leg, first-touch page faults of 2.4 GB another 16 s)
-            return _by_shape[s]
-        n = math.prod(s)
-        t = _by_shape[s] = base.repeat(-(-n // base.numel()))[:n].view(*s)
-        return t
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
     sd = {}
-    pre = 'model.layers.0'
-    for e in ('vision', 'language'):
-        sd[f'{pre}.self_attn.{e}_expert_query_key_value.weight'] = r(3 * h, h)
-        sd[f'{pre}.self_attn.{e}_expert_dense.weight'] = r(h, h)
-        for nm, (o, ii) in dict(gate_proj=(i, h), up_proj=(i, h), down_proj=(h, i)).items():
-            sd[f'{pre}.mlp.{e}_mlp.{nm}.weight'] = r(o, ii)
-    sd[f'{pre}.input_layernorm.weight'] = torch.ones(h)
-    sd[f'{pre}.post_attention_layernorm.weight'] = torch.ones(h)
-    vp = 'v.0'
-    sd.update({f'{vp}.attention.query_key_value.weight': r(3 * d, d), f'{vp}.attention.query_key_value.bias': torch.zeros(3 * d),
-               f'{vp}.attention.dense.weight': r(d, d), f'{vp}.attention.dense.bias': torch.zeros(d),
-               f'{vp}.mlp.fc1.weight': r(f, d), f'{vp}.mlp.fc1.bias': torch.zeros(f), f'{vp}.mlp.fc2.weight': r(d, f),
-               f'{vp}.mlp.fc2.bias': torch.zeros(d), f'{vp}.input_layernorm.weight': torch.ones(d), f'{vp}.input_layernorm.bias': torch.zeros(d),
-               f'{vp}.post_attention_layernorm.weight': torch.ones(d), f'{vp}.post_attention_layernorm.bias': torch.zeros(d)})
-    sd['lm_head.weight'] = r(cfg.vocab_size, h)
-    tt = torch.zeros(1, L, dtype=torch.long)
-    tt[0, 1:1 + Np + 2] = 1
-    pos = torch.arange(L)[None]
-    am = torch.ones(1, L, dtype=torch.bool)
-    cos, sin = O.rope_tables(h // cfg.num_attention_heads, L, torch.float32)
+    for k, v in m.state_dict().items():
+        if not v.is_floating_point():
+            sd[k] = torch.zeros(v.shape, dtype=v.dtype)
+            continue
+        n = v.numel()
+        if k.endswith(('norm.weight', 'layernorm.weight', 'norm1.weight', 'norm2.weight')) or ('norm' in k.rsplit('.', 2)[-2] and k.endswith('.weight')):
+            t = torch.ones(v.shape)
+        else:
+            t = base.repeat(-(-n // base.numel()))[:n].view(v.shape).clone()
+        sd[k] = t.requires_grad_(k in trainable)
+    batch = mk([workload['image']], [workload['patch']], [workload['pool']], [workload['text']], tok=tok, seed=5, grounding=workload['sam'],
+               n_pairs=4, instance=[False], device=torch.device('cpu'))
+    batch['image'] = [x.float() for x in batch['image']]
+    return sd, batch, c
 
-    def t_lm():
-        x = r(1, L, h).clone().requires_grad_()
-        y = O.decoder_layer(sd, ocfg, pre, x, tt, pos, am, cos, sin)
-        y.sum().backward()
 
-    def t_vit():
-        x = r(Nv, d).clone().requires_grad_()
-        O.vit_layer(sd, ocfg, vp, x, [Nv]).sum().backward()
+def cpu_baseline(workload: dict, cfg, tok) -> dict:
+    """The CPU oracle (oracle/vividmed.py, pinned against the reference) timed on the host cores on a bounded sample of the SAME
+    workload: its whole `training_step` (mmmm.py:296-352: ViT-E + GLU adapter + decoder + lm_head / weighted CE + SAM-B mask head and
+    losses, forward AND backward, LoRA r64 on every linear) for ONE image at the TRUE layer widths with 1 + 1 and with 2 + 2 layers.
+    Only the depth is extrapolated: T(32 + 63) = T(1 + 1) + (31 r + 62 (1 - r)) (T(2 + 2) - T(1 + 1)), r = the decoder layer's share of
+    the algorithmic FLOPs of one decoder + one ViT-E layer. Reported baseline, not a target."""
+    from oracle import vividmed as O
+    ncpu = os.cpu_count() or 1
+    vc = cfg.vision_config
 
-    def t_head():
-        x = r(L, h).clone().requires_grad_()
-        lg = torch.nn.functional.linear(x, sd['lm_head.weight']).float()
-        O.weighted_ce(lg, torch.randint(0, cfg.vocab_size, (L,), generator=g), torch.ones(L)).backward()
+    def step_cfg(c):
+        ocfg = O.Cfg(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                     num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads, rms_norm_eps=c.rms_norm_eps,
+                     vision=O.VisionCfg(hidden_size=vc['hidden_size'], num_heads=vc['num_heads'], num_hidden_layers=c.vision_config['num_hidden_layers'],
+                                        intermediate_size=vc['intermediate_size'], layer_norm_eps=vc['layer_norm_eps'],
+                                        patch_size=tuple(vc['patch_size']), pos_embed_shape=tuple(vc['pos_embed_shape']), in_channels=vc['in_channels']))
+        if not workload['sam']:
+            return O.StepCfg(lm=ocfg, sam=None, isam=None, mask_loss=None, isam_loss=None, bop_token_id=tok.bop_token_id, eop_token_id=tok.eop_token_id)
+        return O.StepCfg(lm=ocfg, sam=O.SamCfg(), isam=O.SamCfg(num_instances=6, instance=True),
+                         mask_loss=dict(dice_weight=2, focal_weight=2, focal_gamma=2), isam_loss=O.ISamLossCfg(),
+                         bop_token_id=tok.bop_token_id, eop_token_id=tok.eop_token_id)
 
-    def t_small():          # the same three pieces on a 32-token problem: pages in the BLAS / autograd paths, costs milliseconds
-        xs = r(1, 32, h).clone().requires_grad_()
-        O.decoder_layer(sd, ocfg, pre, xs, tt[:, :32], pos[:, :32], am[:, :32], cos, sin).sum().backward()
-        xv = r(33, d).clone().requires_grad_()
-        O.vit_layer(sd, ocfg, vp, xv, [33]).sum().backward()
+    def run(n_dec, n_vit):
+        sd, batch, c = _oracle_state_and_batch(workload, cfg, n_dec, n_vit, tok)
+        t0 = time.perf_counter()
+        loss, _ = O.training_step(sd, step_cfg(c), batch, rope_dtype=torch.float32)
+        loss.backward()
+        return time.perf_counter() - t0
 
     # thread count: all host cores is not the fastest choice for layer-sized GEMMs on a many-core box (round 1 measured 27 s per
-    # layer with 256 threads, vs 4.7 s on the 8 cores of the development container) — probe a few counts on the small problem
-    # and use the fastest; `cores` reports the count actually used
-    best, best_t = cores, None
-    for n in sorted({min(cores, c) for c in (8, 16, 32, 64, cores)}):
+    # layer with 256 threads, vs 4.7 s on the 8 cores of the development container): probe on one 2048 x 4096 x 4096 product
+    a_, b_ = torch.randn(2048, 4096), torch.randn(4096, 4096)
+    best, best_t = 1, None
+    for n in sorted({min(ncpu, k) for k in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(n)
-        t_small()
+        a_ @ b_
         t0 = time.perf_counter()
-        t_small()
+        a_ @ b_
         dt_ = time.perf_counter() - t0
         if best_t is None or dt_ < best_t:
             best, best_t = n, dt_
     torch.set_num_threads(best)
-    cores = best
-
-    def clock(fn):
-        t0 = time.perf_counter()
-        fn()
-        return time.perf_counter() - t0
-
-    a, b, c = clock(t_lm), clock(t_vit), clock(t_head)
-    per_image = cfg.num_hidden_layers * a + vc['num_hidden_layers'] * b + c
-    return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': (f'oracle fp32 fwd+bwd of 1 true-width decoder layer (L={L}) {a:.2f}s, 1 true-width ViT layer (Nv={Nv}) {b:.2f}s, '
-                       f'lm_head+CE {c:.2f}s on 1 image, one run each after a small-shape warm-up, {cores} of {os.cpu_count()} host threads '
-                       f'(fastest of a probe); extrapolated x{cfg.num_hidden_layers}/x{vc["num_hidden_layers"]} layers (grounding heads not included)')}
+    t11 = run(1, 1)
+    t22 = run(2, 2)
+    # one decoder layer's share of (decoder layer + ViT-E layer), from the workload's own FLOP formulas (SURVEY §8d)
+    one = dict(workload, mixed=False)
+    import copy
+    c1 = copy.deepcopy(cfg); c1.num_hidden_layers = 1; c1.vision_config = dict(vc, num_hidden_layers=0)
+    c2 = copy.deepcopy(cfg); c2.num_hidden_layers = 0; c2.vision_config = dict(vc, num_hidden_layers=1)
+    c0 = copy.deepcopy(cfg); c0.num_hidden_layers = 0; c0.vision_config = dict(vc, num_hidden_layers=0)
+    f0 = train_flops_per_sample(one, c0, False)
+    fd, fv = train_flops_per_sample(one, c1, False) - f0, train_flops_per_sample(one, c2, False) - f0
+    r = fd / (fd + fv)
+    delta = max(t22 - t11, 0.0)
+    nl, nv = cfg.num_hidden_layers, vc['num_hidden_layers']
+    per_image = t11 + ((nl - 1) * r + (nv - 1) * (1 - r)) * delta
+    return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': best, 'kind': 'port',
+            'sample': (f'oracle fp32 training_step (forward + backward, LoRA r64, {"SAM-B mask head + losses" if workload["sam"] else "no grounding heads"}) of ONE image '
+                       f'of {workload["desc"].split(":")[0]} at the true widths: 1 + 1 layers {t11:.1f} s, 2 + 2 layers {t22:.1f} s, {best} of {ncpu} host threads '
+                       f'(fastest of a probe); depth extrapolated to {nl} + {nv} layers with the decoder layer taking {r:.2f} of the increment (FLOP share)')}
 
 
 def self_launch(n: int) -> int:
@@ -630,7 +637,7 @@ def main():
         if also:
             out['also'] = also
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(w, model.config)
+            out['cpu_baseline'] = cpu_baseline(w, model.config, tok)
         print(json.dumps(out), file=reserve_stdout(), flush=True)
     if use_dist:
         dist.destroy_process_group()
