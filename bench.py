@@ -50,11 +50,13 @@ WORKLOADS = {
 }
 
 
-def train_flops_per_sample(w: dict, cfg, sam: bool) -> float:
-    """algorithmic training FLOPs per sample, recompute excluded (SURVEY.md §8d formulas)"""
+def train_flops_per_sample(w: dict, cfg, sam: bool, head_rows: str = 'all') -> float:
+    """algorithmic training FLOPs per sample, recompute excluded (SURVEY.md §8d formulas). `head_rows`: 'all' = lm_head over all L rows
+    (the formula of SURVEY §8d: the reference computes every row's logits, mmmm.py:333-341 reads the labelled ones), a number = over
+    that many rows per sample (what this build executes: `lm_head` + CE on the labelled rows only, modeling_cogvlm.py)"""
     if w.get('mixed'):
         a = {k: v for k, v in w.items() if k != 'mixed'}
-        return 0.5 * (train_flops_per_sample(a, cfg, sam) + train_flops_per_sample(WORKLOADS['phase-grg-3d'], cfg, sam))
+        return 0.5 * (train_flops_per_sample(a, cfg, sam, head_rows) + train_flops_per_sample(WORKLOADS['phase-grg-3d'], cfg, sam, head_rows))
     vc = cfg.vision_config
     d, f, h, i = vc['hidden_size'], vc['intermediate_size'], cfg.hidden_size, cfg.intermediate_size
     img, patch, pool = w['image'], w['patch'], w['pool']
@@ -69,7 +71,7 @@ def train_flops_per_sample(w: dict, cfg, sam: bool) -> float:
     F_glu = 2 * Np * (d * h + 3 * h * i)
     F_lm_lin = nl_l * 2 * L * (4 * h * h + 3 * h * i)
     F_lm_attn = nl_l * 2 * L * L * h
-    F_head = 2 * L * h * cfg.vocab_size
+    F_head = 2 * (L if head_rows == 'all' else float(head_rows)) * h * cfg.vocab_size
     F_lora = 2 * L * 64 * ((h + 3 * h) + (h + h) + 3 * (h + i)) * nl_l + 2 * Nv * 64 * ((d + 3 * d) + (d + d) + 2 * (d + f)) * nl_v
     # frozen linears: fwd + dgrad (x2); trainable linears / LoRA / lm_head / attention: x3; frozen SAM + iSAM: x2 each
     total = 2 * (F_vit_lin + F_glu + F_lm_lin) + 3 * (F_head + F_lora + F_vit_attn + F_lm_attn)
@@ -274,27 +276,37 @@ def gemm_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+ALSO_BATCH = {'model-hr-2d': 4, 'model-hr-3d': 4}      # per-GPU batch of the high-resolution workloads (activations of 3 137 / 4 609 ViT tokens per image)
+
+
 def run_also(workloads: list, args) -> list:
-    """other workloads of BASELINE.json (phase-vlm: the one the north_star's 50 % target is quoted on) measured by child processes of
-    this script, one after the other, BEFORE this process touches the GPU (a child needs the HBM to itself). Returns their
-    condensed lines."""
+    """other workloads of BASELINE.json (phase-vlm: the one the north_star's 50 % target is quoted on; configs[3] phase-grg-3d and
+    configs[4] model-hr-2d in bf16 and with the e4m3 frozen-weight GEMMs, spelled `model-hr-2d:fp8`) measured by child processes of this
+    script, one after the other, BEFORE this process touches the GPU (a child needs the HBM to itself). A child is only started while
+    `--also-budget` seconds of wall clock last: the default run has to stay within minutes. Returns their condensed lines."""
     import subprocess
     out = []
-    for wl in workloads:
-        if wl not in WORKLOADS:
-            raise SystemExit(f'--also: unknown workload {wl}')
+    t_all = time.perf_counter()
+    for spec in workloads:
+        wl, _, mode = spec.partition(':')
+        if wl not in WORKLOADS or mode not in ('', 'fp8'):
+            raise SystemExit(f'--also: unknown workload {spec}')
+        if time.perf_counter() - t_all > args.also_budget:
+            out.append({'workload': spec, 'skipped': f'--also-budget {args.also_budget:.0f} s used up by the workloads before it'})
+            continue
+        batch = min(args.batch, ALSO_BATCH.get(wl, args.batch))
         cmd = [sys.executable, str(Path(__file__).resolve()), '--workload', wl, '--steps', '12', '--warmup', '3', '--no-cpu-baseline',
-               '--no-kernel-events', '--also', '', '--batch', str(args.batch), '--checkpointing', args.checkpointing,
-               '--hbm-fraction', str(args.hbm_fraction)]
+               '--no-kernel-events', '--no-peak-probe', '--also', '', '--batch', str(batch), '--checkpointing', args.checkpointing,
+               '--hbm-fraction', str(args.hbm_fraction)] + (['--fp8'] if mode == 'fp8' else [])
         t0 = time.perf_counter()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         line = next((ln for ln in r.stdout.splitlines() if ln.startswith('{')), None)
         if r.returncode != 0 or line is None:
-            out.append({'workload': wl, 'error': f'exit code {r.returncode}'})
+            out.append({'workload': spec, 'error': f'exit code {r.returncode}'})
             continue
         j = json.loads(line)
-        out.append({'workload': wl, 'description': j['config']['description'], 'value': j['value'], 'unit': j['unit'],
-                    'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'],
+        out.append({'workload': spec, 'description': j['config']['description'], 'dtype': j['dtype'], 'per_gpu_batch': batch, 'value': j['value'],
+                    'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'],
                     'mfma_utilisation_step': j['mfma_utilisation_step'], 'model_tflops_per_image': j['model_tflops_per_image'],
                     'gradient_checkpointing': j['config']['gradient_checkpointing'], 'wgrad_side_stream': j['config']['wgrad_side_stream'],
                     'wall_s': round(time.perf_counter() - t0, 1)})
@@ -399,7 +411,10 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP event bracketing (roofline)')
     ap.add_argument('--no-calibrate', action='store_true',
                     help='counter-collection runs only (tools/pmc_step.sh): keep the planning step but skip the calibration steps that follow it')
-    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed'),
+    ap.add_argument('--no-peak-probe', action='store_true', help='skip the 2 s MFMA peak measurement (roofline.peak_measured)')
+    ap.add_argument('--also-budget', type=float, default=float(os.environ.get('VM_BENCH_ALSO_BUDGET', '330')),
+                    help='seconds of wall clock for the --also children together: a child is only started while the budget lasts (the rest are reported as skipped)')
+    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8'),
                     help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
                          "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
     args = ap.parse_args()
@@ -411,7 +426,7 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     also = []
     if args.also and args.gpus == 1 and 'WORLD_SIZE' not in os.environ and not args.dry_run_cpu and args.depth_scale == 1.0 and not args.fp8:
-        also = run_also([w for w in args.also.split(',') if w and w != args.workload], args)
+        also = run_also([w for w in args.also.split(',') if w and w != args.workload], args)       # (`model-hr-2d:fp8` != `model-hr-2d`)
     reserve_stdout()          # (after the self-launch branch: the child ranks inherit the real stdout) before anything that may print from C
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -544,6 +559,14 @@ def main():
         loss = step()
     if args.checkpointing == 'hbm':
         plan = 'hbm budget %.0f GB: kept/total layers %s' % (ActivationBudget.limit / 2**30, ActivationBudget.last_plan)
+    peak_measured = None
+    if rank == 0 and world == 1 and not args.no_peak_probe:
+        # the box's own sustained bf16 MFMA rate (2 s of bare MFMAs on random operands, every CU busy): nominal 2.5 PFLOP/s assumes
+        # 2.4 GHz, the chip holds 1.9-1.95 GHz under matrix load (guide: DVFS give-back). Outside the timed region, then two untimed
+        # steps so that the caches / clocks of the step are back before timing starts.
+        peak_measured = K.ubench_mfma_bf16(2.0)
+        for _ in range(2):
+            step()
     use_events = not args.no_kernel_events
     if use_events:
         K.prof_reset()
@@ -585,7 +608,11 @@ def main():
     if rank == 0:
         images = world * args.batch * args.steps
         value = images / dt
-        fl_sample = train_flops_per_sample(w, model.config, w['sam'])
+        fl_formula = train_flops_per_sample(w, model.config, w['sam'])
+        # lm_head runs on the labelled rows only (the reference reads its logits there, mmmm.py:333-341): count what is executed
+        from mmmm_amd.models.cogvlm import modeling_cogvlm as _mc
+        n_lab = sum(float((b['vlm_inputs']['labels'] != -100).sum()) for b in batches) / (len(batches) * args.batch)
+        fl_sample = train_flops_per_sample(w, model.config, w['sam'], head_rows=n_lab) if _mc.LM_HEAD_LABEL_ROWS else fl_formula
         out = {
             'metric': 'train images/sec/node', 'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -601,8 +628,11 @@ def main():
             'allocator': {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
                          | {'reserved_gb': round(ms1.get('reserved_bytes.all.current', 0) / 2**30, 1)},
             'model_tflops_per_image': fl_sample / 1e12,
+            'model_tflops_per_image_survey_formula': fl_formula / 1e12,
+            'labelled_rows_per_sample': n_lab,
             'mfma_utilisation_step': value / world * fl_sample / 1e12 / PEAK_BF16_TFLOPS,
-            'mfma_utilisation_note': 'algorithmic training FLOPs / dense bf16 peak (2.5 PFLOP/s)' + ('; the e4m3 GEMMs of this run have a 5 PFLOP/s peak' if args.fp8 else ''),
+            'mfma_utilisation_step_survey_formula': value / world * fl_formula / 1e12 / PEAK_BF16_TFLOPS,
+            'mfma_utilisation_note': 'training FLOPs of the work this build executes (lm_head on the labelled rows only; `_survey_formula` counts lm_head over all L rows as SURVEY 8d does) / dense bf16 peak (2.5 PFLOP/s)' + ('; the e4m3 GEMMs of this run have a 5 PFLOP/s peak' if args.fp8 else ''),
         }
         if use_events:
             ms, fl, n = K.prof_collect(hip.PROF_GEMM_BF16)
@@ -620,7 +650,10 @@ def main():
                     traffic_src = (f'profiles/{tf.name} is STALE (kernel sources changed since it was measured: digest {tj.get("source_digest")} '
                                    f'vs {digest}; it held {tj["bytes_per_launch"]:.3e} bytes per launch) — re-run tools/pmc_traffic.sh')
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic,
+                               'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                               'peak_measured': peak_measured, 'frac_of_measured': (ach / peak_measured) if peak_measured else None,
+                               'peak_measured_note': 'sustained rate of bare v_mfma_f32_16x16x32_bf16 on this device, uniform random operands in registers, two waves per SIMD, all CUs, 2 s (second half timed): vm_ubench_mfma_bf16',
+                               'traffic': traffic,
                                'traffic_unit': 'bytes per launch (L2 memory-side, FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
                                'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_flops_per_launch': fl / max(n, 1),
                                'launches': n, 'launch_sample': f'pseudo-random 1 in {args.event_stride} launches of the timed region', 'avg_launch_ms': ms / max(n, 1), 'kernel_time_share': ms * args.event_stride * 1e-3 / dt,

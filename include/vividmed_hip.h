@@ -519,6 +519,14 @@ int vm_attn_bwd_f32(const vm_attn_f32_args* args_host, void* stream);
 int vm_im2col3d(const void* image, int C, int D, int H, int W, int pz, int py, int px,
                 void* cols, int64_t ld, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Measurement helper (bench.py's `roofline.peak_measured`; not on the training path): the sustained rate of bare
+ * v_mfma_f32_16x16x32_bf16 on THIS device with uniform random operands in registers, two waves per SIMD, every CU busy, for about
+ * `seconds` (first half load only, second half timed with HIP events on `stream`). SYNCHRONOUS: returns after the measurement with
+ * TFLOP/s in *tflops_host (host memory). SURVEY.md §8d: "re-measure with an MFMA micro-bench on the box and use the measured peak
+ * alongside" the nominal 2.5 PFLOP/s. */
+int vm_ubench_mfma_bf16(float seconds, float* tflops_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

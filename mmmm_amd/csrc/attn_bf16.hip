@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
 
 // ----------------------------------------------------------------------------- backward: dK, dV (16 keys per wave)
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 1) void attn16_dkv_k(const AttnP p) {
+__global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
   constexpr int ND = HD / 16;
@@ -482,15 +482,8 @@ dim3 grid16(const vm_attn_args* a, int qb) {
   const int pairs8 = (a->n_heads * a->n_seq + 7) / 8 * 8;
   return dim3((unsigned)(pairs8 * ((a->max_seqlen + qb - 1) / qb)));
 }
-// waves per workgroup: 16 (256 positions per block: every K/V (Q/dO) tile a workgroup streams serves twice the positions — these
-// kernels are bound by the bytes their CUs take in through LDS-DMA, 373 MB per ViT-E forward launch with 128-position blocks) unless
-// the sequences are short; VM_ATTN_NW=8 restores round 2's 128-position blocks
-// Measured [r3]: 16 waves are NOT faster (ViT-E forward 83 vs 79 us, the step 314.3 vs 314.0 ms): what bounds these kernels is not the
-// operand stream but the phases of a wave not overlapping (see the stagger above). Default 8; VM_ATTN_NW=16 for A/B runs.
-int attn_nw(const vm_attn_args* a) {
-  static const int forced = [] { const char* e = getenv("VM_ATTN_NW"); return e ? atoi(e) : 8; }();
-  return (forced == 16 && a->max_seqlen > 192) ? 16 : 8;
-}
+// (Measured in round 3 and removed: 256-position blocks of 16 waves — the forward 83 vs 79 us, the step 314.3 vs 314.0 ms; dK / dV would spill
+// 26-49 registers at 16 waves. The backward kernels use 128-position blocks of 8 waves.)
 double attn_flops(const vm_attn_args* a, double mult) {
   // upper bound with every sequence at max_seqlen; bench uses equal-length sequences so it is exact
   const double L = a->max_seqlen;
@@ -575,25 +568,16 @@ int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   if (!fits32(a)) return VM_ERR_UNSUPPORTED;
   AttnP p = to_params(a);
   const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
-  dim3 grid((a->max_seqlen + 127) / 128, a->n_heads, a->n_seq);
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  const int nw = attn_nw(a);
-  static const int dkv_forced = [] { const char* e = getenv("VM_ATTN_DKV_NW"); return e ? atoi(e) : 8; }();
-  const int dkv_nw = (dkv_forced == 16 && nw == 16) ? 16 : 8;
-  p.n_tiles = (a->max_seqlen + nw * 16 - 1) / (nw * 16);
+  p.n_tiles = (a->max_seqlen + 127) / 128;
     ATTN_DISPATCH_HD(a->head_dim,
-                     if (!lds_ok((const void*)attn16_dq_k<HD, 8>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 8>, A16_LDS_DKV) ||
-                         !lds_ok((const void*)attn16_dq_k<HD, 16>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 16>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
+                     if (!lds_ok((const void*)attn16_dq_k<HD, 8>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 8>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
                      hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
                                         (hipStream_t)stream, p, a->n_seq);
-                     if (nw == 16) hipLaunchKernelGGL((attn16_dq_k<HD, 16>), grid16(a, 256), dim3(1024), A16_LDS, (hipStream_t)stream, p);
-                     else hipLaunchKernelGGL((attn16_dq_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS, (hipStream_t)stream, p);
-                     // dK / dV: 164 VGPRs per wave (two accumulator sets): 16 waves per workgroup would spill (26-49 slots), so its blocks stay
-                     // at 128 keys unless VM_ATTN_DKV_NW=16 asks for the spilling form (A/B measurements)
-                     p.n_tiles = (a->max_seqlen + dkv_nw * 16 - 1) / (dkv_nw * 16);
-                     if (dkv_nw == 16) hipLaunchKernelGGL((attn16_dkv_k<HD, 16>), grid16(a, 256), dim3(1024), A16_LDS_DKV, (hipStream_t)stream, p);
-                     else hipLaunchKernelGGL((attn16_dkv_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
+                     hipLaunchKernelGGL((attn16_dq_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS, (hipStream_t)stream, p);
+                     // dK / dV: 164 VGPRs per wave (two accumulator sets), one 8-wave workgroup per CU
+                     hipLaunchKernelGGL((attn16_dkv_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
   VM_LAUNCH_CHECK();
   return VM_OK;

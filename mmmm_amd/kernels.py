@@ -183,6 +183,13 @@ def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Ten
     return out
 
 
+def ubench_mfma_bf16(seconds: float = 2.0) -> float:
+    """sustained TFLOP/s of bare bf16 MFMAs on the current device (vm_ubench_mfma_bf16: random operands, ~`seconds`, synchronous)"""
+    out = C.c_float(0.0)
+    hip.call('vm_ubench_mfma_bf16', float(seconds), C.addressof(out), stream())
+    return float(out.value)
+
+
 def _f32_mode_from_env() -> int:
     try:
         v = int(os.environ.get('VM_F32_SPLIT', '3'))

