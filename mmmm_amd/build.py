@@ -19,8 +19,9 @@ LIB_DIR = ROOT / 'lib'
 LIB_PATH = LIB_DIR / 'libvividmed_hip.so'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-CFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function',
-          '-fgpu-flush-denormals-to-zero' if False else '-DVM_KEEP_DENORMS']
+# VM_BUILD_DEFINES: extra -D flags of diagnostic builds (VM_GEMM_DEBUG_BUILD: the GEMM timing-experiment branches, tools/README.md)
+CFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function', '-DVM_KEEP_DENORMS',
+          *os.environ.get('VM_BUILD_DEFINES', '').split()]
 
 
 def _sources() -> list[Path]:

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;              // split-K: this workgroup's K range
   const int kloc = p.ksplit > 1 ? min(p.kchunk, p.K - kbeg) : p.K;
   const int kskip = kbeg * ESZ;
-  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b + kskip, (p.dbg & 1) ? 0 : nrows * lda_b - kskip);
-  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b + kskip, (p.dbg & 1) ? 0 : ncols * ldb_b - kskip);
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b + kskip, VM_DBG(p, 1) ? 0 : nrows * lda_b - kskip);
+  __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b + kskip, VM_DBG(p, 1) ? 0 : ncols * ldb_b - kskip);
 
   const int kt_ext = p.K2 / BKE;
   const int kt_main = kloc / BKE;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   if (t < kt_total) kstep(t, F_, F_);                         // last main tile
 
   // ---- epilogue
-  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
+  if VM_DBG(p, 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
     const bool splitk = p.ksplit > 1;
@@ -486,7 +486,11 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bm = bm64 ? 64 : BM;
   p.tiles_m = (a->M + bm - 1) / bm + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
+#ifdef VM_GEMM_DEBUG_BUILD
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+#else
+  p.dbg = 0;
+#endif
   const int grid = p.tiles_m * p.tiles_n;
   const int kind = esz == 2 ? VM_PROF_GEMM_BF16 : VM_PROF_GEMM_F32;
   if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
@@ -572,7 +576,11 @@ int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_
   p.ksplit = 1; p.kchunk = a->K;
   p.b_nn = 0;
   p.row_scale = row_scale; p.col_scale0 = col_scale; p.col_scale1 = col_scale_1 ? col_scale_1 : col_scale;
+#ifdef VM_GEMM_DEBUG_BUILD
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+#else
+  p.dbg = 0;
+#endif
   int big = big_tile_rows(a->M, a->N, a->K / 2 + a->K2, segmented);          /* rounds x cost in bf16-equivalent K-tiles */
   if (!big) big = 256;                                                        /* the fp8 main loop exists in the 256-column kernel only */
   void* tok = nullptr;

@@ -100,7 +100,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
   constexpr int WR = 32 * MI;          // rows of one wave-row (128 or 96)
   constexpr int HR = 16 * MI;          // rows of one slab pass
   const int frow = lane & 15, fq = lane >> 4;
-  if (p.dbg & 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
+  if VM_DBG(p, 32) { if (acc[0][0][0] == 123.456f) ((float*)p.C)[0] = 1.f; return; }   // timing experiment: no C traffic
   const void* bias = seg ? p.bias1 : p.bias0;
   if (OUT_F32) {
 #pragma unroll
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   const char* B2w = seg ? p.B2_1 : p.B2_0;
 
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, (p.dbg & 1) ? 0 : nrows * lda_b);
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, VM_DBG(p, 1) ? 0 : nrows * lda_b);
   // NT: rows n0 .. n0 + ncols of B [N, K]; NN: all K contraction rows of B [K, N], shifted to output column n0
-  const __amdgpu_buffer_rsrc_t rB = BNN ? make_rsrc(Bw, (int64_t)n0 * 2, (p.dbg & 1) ? 0 : (int)(((int64_t)p.K * ldb_b - (int64_t)n0 * 2)))
-                                        : make_rsrc(Bw, (int64_t)n0 * ldb_b, (p.dbg & 1) ? 0 : ncols * ldb_b);
+  const __amdgpu_buffer_rsrc_t rB = BNN ? make_rsrc(Bw, (int64_t)n0 * 2, VM_DBG(p, 1) ? 0 : (int)(((int64_t)p.K * ldb_b - (int64_t)n0 * 2)))
+                                        : make_rsrc(Bw, (int64_t)n0 * ldb_b, VM_DBG(p, 1) ? 0 : ncols * ldb_b);
   // F8: the main operands are e4m3 bytes — a 128-byte LDS row holds 128 k instead of 64, everything else (DMA, swizzle, phases) is
   // unchanged; the LoRA extension tiles stay bf16
   const int kt_ext = p.K2 / 64, kt_main = F8 ? p.K / 128 : p.K / 64, kt_total = kt_ext + kt_main;

@@ -8,6 +8,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #endif
 constexpr int GROUP_M = VM_GROUP_M;
 
+// Timing experiments on the GEMM kernels (operands without traffic, epilogue without stores, no XCD remap: the knock-out measurements
+// of DESIGN.md section 5) are compiled in only with -DVM_GEMM_DEBUG_BUILD (then selected at run time by VM_GEMM_DEBUG=<bits>); the
+// shipped library carries none of their branches.
+#ifdef VM_GEMM_DEBUG_BUILD
+#define VM_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define VM_DBG(p, bit) (false)
+#endif
+
 struct GemmParams {
   const char* A; int64_t lda;          // leading dimensions in ELEMENTS
   const char* B0; const char* B1; int64_t ldb;
@@ -28,7 +37,7 @@ struct GemmParams {
   const float* row_scale; const float* col_scale0; const float* col_scale1;
   int b_nn;             // gemm256_k<.., BNN>: the main B operand is stored [contraction][output column] (a weight as it sits in HBM, for dx = dy W)
   int ksplit, kchunk;   // split-K (fp32 atomics into a zeroed C): blockIdx.y owns K range [y*kchunk, (y+1)*kchunk)
-  int dbg;   // timing experiments only: bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
+  int dbg;   // timing-experiment builds only (-DVM_GEMM_DEBUG_BUILD): bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
 };
 
 // Buffer resource from provably wave-uniform words (avoids hipcc's waterfall loops, guide T20).
@@ -46,7 +55,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, in
 __device__ __forceinline__ void gemm_tile_id(const GemmParams& p, int& tm, int& tn) {
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
-  if (!(p.dbg & 2)) {
+  if (!VM_DBG(p, 2)) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -189,7 +198,7 @@ __device__ __forceinline__ void epi_flush(const char* slab, const GemmParams& p,
   const int ch = lane % CPR, rr = lane / CPR;
   const unsigned short* rp = (const unsigned short*)p.residual;
   const bool vec_ok = (p.ldc % 8 == 0) && (n0 % 8 == 0) && (!rp || p.ldr % 8 == 0);
-  if (p.dbg & 64) return;                       // timing experiment: epilogue without stores
+  if VM_DBG(p, 64) return;                       // timing experiment: epilogue without stores
   if (vec_ok && cols_valid >= COLS) {
     // full-width column block: whole 16-byte chunks; a ragged last row tile only predicates rows
     unsigned short* cbase = (unsigned short*)p.C + (m0 + rr) * p.ldc + n0 + ch * 8;

@@ -895,16 +895,14 @@ static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx
   static bool attr_set = false;
   if (!attr_set) {
     const int one = DN_BM * ROWB;
-    if (hipFuncSetAttribute((const void*)lora_down_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * one) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
+    if (hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
         hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
         hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU_BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess ||
         hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess)
       return VM_ERR_LAUNCH;
     attr_set = true;
   }
-  // VM_LORA_DOWN_DEEP=1: four-stage ring for single-pass grids (measured neutral inside the step: 320.3 vs 320.5 ms, A B A B)
-  static const int deep = [] { const char* e = getenv("VM_LORA_DOWN_DEEP"); return e ? atoi(e) : 0; }();
+  // (measured in round 3 and removed: a four-stage ring for single-pass grids — 320.3 vs 320.5 ms per step)
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
   const dim3 g(grid, p.ksplits), b(256);
@@ -915,8 +913,7 @@ static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx
     case VM_LD_GELU_BWD: hipLaunchKernelGGL((lora_down_k<2, VM_LD_GELU_BWD>), g, b, 2 * 3 * one, st, p); break;
     case VM_LD_SILU_MUL: hipLaunchKernelGGL((lora_down_k<2, VM_LD_SILU_MUL>), g, b, 2 * 3 * one, st, p); break;
     default:
-      if (deep && grid * p.ksplits <= 320) hipLaunchKernelGGL((lora_down_k<4>), g, b, 4 * 2 * one, st, p);
-      else hipLaunchKernelGGL((lora_down_k<2>), g, b, 2 * 2 * one, st, p);
+      hipLaunchKernelGGL((lora_down_k<2>), g, b, 2 * 2 * one, st, p);
   }
   if (p.ksplits > 1)
     hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -6,7 +6,7 @@
 # per counter group (MI355X_MICROARCH.md 'rocprofv3 PMC slots'); FETCH_SIZE and WRITE_SIZE in passes of their own.
 # Writes gpurun_out/<tag>_pmc.json (per kernel and grid: per-launch averages + derived ratios) and <tag>_gemm_traffic.json.
 # usage (via gpurun): bash tools/pmc_step.sh <tag>
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
@@ -15,7 +15,7 @@ for grp in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
            "FETCH_SIZE" \
            "WRITE_SIZE"; do
   i=$((i+1)); rm -rf /tmp/pmc_g$i
-  timeout 600 rocprofv3 --pmc $grp --kernel-include-regex 'gemm256_k|attn16_' --output-format csv -d /tmp/pmc_g$i -o t -- python3 $R/bench.py --steps 1 --warmup 0 --no-calibrate --no-cpu-baseline --no-kernel-events --also '' > /tmp/pmc_g$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --kernel-include-regex 'gemm256_k|attn16_|fwd_k' --output-format csv -d /tmp/pmc_g$i -o t -- python3 $R/bench.py --steps 1 --warmup 0 --no-calibrate --no-cpu-baseline --no-kernel-events --no-peak-probe --also '' > /tmp/pmc_g$i.log 2>&1
   tail -2 /tmp/pmc_g$i.log | cut -c1-200
 done
 cd $R
@@ -25,7 +25,7 @@ tag = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in sorted(glob.glob("/tmp/pmc_g*/t_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(gemm256_k<[\w, ]+>|attn16_\w+<\d+>)", r["Kernel_Name"])
+        m = re.search(r"(gemm256_k<[\w, ]+>|attn16_\w+<\d+>|fwd_k<\d+, \w+>)", r["Kernel_Name"])
         if not m: continue
         grid = int(r.get("Grid_Size", 0) or 0) // max(int(r.get("Workgroup_Size", 1) or 1), 1)
         a = agg[f"{m.group(1)} x{grid}"][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])

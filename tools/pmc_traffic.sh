@@ -6,7 +6,7 @@
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-events > $R/gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-events --no-peak-probe --also "" > $R/gpurun_out/pmc_$c.log 2>&1
 done
 cd $R
 python3 - <<PY

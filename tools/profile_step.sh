@@ -5,7 +5,7 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o vm -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --also '' "$@" > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o vm -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-events --no-peak-probe --also '' "$@" > /tmp/prof_$TAG.log 2>&1
 grep '^{' /tmp/prof_$TAG.log | cut -c1-260
 cd $R
 TRACE=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
