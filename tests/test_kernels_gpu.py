@@ -351,7 +351,11 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
     torch.manual_seed(11)
     cfg = Namespace(hidden_size=256, num_heads=4, intermediate_size=512, layer_norm_eps=1e-6)
     layer = TransformerLayer(cfg).to(dev).bfloat16()
-    apply_lora(layer, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.05, use_rslora=True))
+    from mmmm_amd.models.lora import Linear as _Lin
+    targets = [n for n, mod in layer.named_modules() if isinstance(mod, _Lin)]
+    norms = [n for n, mod in layer.named_modules() if 'norm' in n.rsplit('.', 1)[-1]]
+    apply_lora(layer, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.05, use_rslora=True), targets, norms)
+    assert len(targets) == 4
     with torch.no_grad():
         for n, p in layer.named_parameters():
             if 'lora_B' in n:
