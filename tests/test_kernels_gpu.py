@@ -1114,3 +1114,10 @@ def test_gelu_table_kernels_equal_the_arithmetic_kernels_on_every_bf16_value(dev
     dr = torch.randn(n, device=dev, generator=g).bfloat16()
     assert torch.equal(K.gelu(xr)[-5:], K.gelu(xr[-5:].clone()))
     assert torch.equal(K.gelu_bwd(xr, dr)[-5:], K.gelu_bwd(xr[-5:].clone(), dr[-5:].clone()))
+
+
+def test_mfma_peak_probe_returns_a_plausible_rate(dev, K):
+    """vm_ubench_mfma_bf16 (bench.py's roofline.peak_measured): bare bf16 MFMAs on random operands for a fraction of a second — an MI355X
+    sustains between ~1.5 and 2.5 PFLOP/s there (nominal 2.5 at 2.4 GHz; the clock under matrix load is lower)"""
+    r = K.ubench_mfma_bf16(0.4)
+    assert 1000.0 < r < 2600.0, r
