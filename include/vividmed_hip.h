@@ -397,6 +397,7 @@ int vm_ce_bwd(const void* logits, int64_t ld, const int64_t* labels, const float
  * *sequence positions*; `row_of_pos` (optional) maps a sequence position to
  * its physical row (expert-sorted layout), NULL = identity.
  * out: [rows, H, hd] (ldo), lse: [H, total_pos] fp32.
+ * With `row_of_pos` the forward keeps the sequence's slice of it in LDS: max_seqlen <= 16 384 (VM_ERR_UNSUPPORTED beyond).
  */
 typedef struct vm_attn_args {
   const void* q; const void* k; const void* v; void* out;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fwd_k(const AttnP p) {
   int* rowtab = nullptr;
   if (p.row_of_pos) {                            // the sequence's physical rows -> LDS (behind rings and slabs)
     rowtab = reinterpret_cast<int*>(smem + RING_LDS);
-    for (int i = tid; i < kv_end; i += NW * 64) rowtab[i] = p.row_of_pos[seq0 + i];
+    for (int i = tid; i < min(seqlen, nt * 64); i += NW * 64) rowtab[i] = p.row_of_pos[seq0 + i];      // every position a staged tile can hold
     __syncthreads();
   }
 
