@@ -136,6 +136,30 @@ __device__ __forceinline__ bf16x8_t frag16_tr(const char* tile, int rbase, int b
   const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + tile_off16(rowB, chunk) + sub));
   return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+// frag16_tr through inline assembly. hipcc cannot see what a ds_read_b64_tr_b16 BUILTIN reads: it drains the LDS-DMA queue (vmcnt(0)) in front
+// of the first one after a DMA issue — i.e. in the middle of every tile, under half of the DMA's flight — and waits for each pair of
+// reads on its own (lgkmcnt(0) per MFMA pair, nothing in flight behind it). The assembly form is invisible to it: a whole batch is
+// issued, lands under the exponentials, and is complete only behind tr_wait() (a wait-only statement + sched_barrier: guide §5.7 (iii)).
+// tr_lane_base(): the lane's address for column block b of tile rows 4 g + (i >> 2) (+ 16: immediate 16 ROWB); 32-row groups, the
+// second operand tile and the stage are added by the caller (lane-uniform) or ride as immediates.
+// Column block b sits at bits 5..7 of the address as b ^ (row & 7): one lane base (block 0), "^ (b << 5)" per block (the stage base is
+// 256-byte aligned and every other term leaves those bits alone).
+__device__ __forceinline__ unsigned tr_lane_base(const char* smem, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int rowA = 4 * g + (i >> 2);
+  return (unsigned)(size_t)smem + rowA * ROWB + ((rowA & 7) << 5) + (((i & 3) >> 1) << 4) + ((i & 1) << 3);
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8_t tr_asm(unsigned addr) {
+  s16x4_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(IMM));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(IMM + 16 * ROWB));
+  return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ void tr_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ bf16x8_t pack2(const f32x4_t& a, const f32x4_t& b) {
   u16x8_t r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
   return __builtin_bit_cast(bf16x8_t, r);
@@ -203,7 +227,7 @@ __device__ __forceinline__ bool a16_block(const AttnP& p, int& tile, int& head, 
 namespace {
 
 // ----------------------------------------------------------------------------- backward: dQ (16 queries per wave)
-template <int HD, int NW>
+template <int HD, int NW, int TRV>
 __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
   constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
   const int ldk_b = (int)p.ldk * 2, ldv_b = (int)p.ldv * 2;
   StageLane sl;
   sl.init<HD, NW>(head, wave, lane);
+  const unsigned trb = tr_lane_base(smem, lane);
   int pr[2];
   a16_rows<NW>(p, seq0, seqlen, 0, wave, lane, pr);
   a16_stage<NW>(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
@@ -266,6 +291,51 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
     const char* sK = smem + buf * A16_STAGE;
     const char* sV = sK + 64 * ROWB;
     const int kv0 = t * 64;
+    const bool edge = kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16);
+    const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
+    if constexpr (TRV != 0) {
+      // per 32-key half: S^T / dP^T (16 MFMAs), the half's transposed K fragments issued under the exponentials, dQ (ND MFMAs)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        f32x4_t sa[2], dp[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * c + jj;
+          sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, 0, lane), qf[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sV, 16 * j, 0, lane), dof[0], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int s = 1; s < KS; ++s) {
+            sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sK, 16 * j, s, lane), qf[s], sa[jj], 0, 0, 0);
+            dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sV, 16 * j, s, lane), dof[s], dp[jj], 0, 0, 0);
+          }
+        }
+        // (two batches: the 128-VGPR budget of 16 waves per CU has no room for ND fragments beside Q, dO and dQ)
+        constexpr int NB0 = ND < 4 ? ND : 4;
+        bf16x8_t tk[NB0], tk1[ND - NB0 + 1];
+        const unsigned ad = trb + buf * A16_STAGE + c * 32 * ROWB;
+#pragma unroll
+        for (int b = 0; b < NB0; ++b) tk[b] = tr_asm<0>(ad ^ (b << 5));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pr_ = fast_exp2(__builtin_fmaf(sa[jj][r], sc, -lse2));
+            if (edge) pr_ = (kv0 + 32 * c + 16 * jj + 4 * g + r <= lim) ? pr_ : 0.f;
+            sa[jj][r] = pr_ * (dp[jj][r] - dlt);
+          }
+        const bf16x8_t df = pack2(sa[0], sa[1]);
+        tr_wait();
+#pragma unroll
+        for (int b = NB0; b < ND; ++b) tk1[b - NB0] = tr_asm<0>(ad ^ (b << 5));
+#pragma unroll
+        for (int b = 0; b < NB0; ++b) dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[b], df, dq[b], 0, 0, 0);
+        if constexpr (ND > NB0) {
+          tr_wait();
+#pragma unroll
+          for (int b = NB0; b < ND; ++b) dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk1[b - NB0], df, dq[b], 0, 0, 0);
+        }
+      }
+    } else {
     f32x4_t sa[4], dp[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -278,8 +348,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
       }
     }
     // dS^T = P ∘ (dP^T − delta)   (the softmax scale is applied once, on dQ)
-    const bool edge = kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16);
-    const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -295,6 +363,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
       for (int b = 0; b < ND; ++b)
         dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sK, 32 * c, b, lane), df, dq[b], 0, 0, 0);
     }
+    }
     A16_WAIT_ALL();
     __syncthreads();
   }
@@ -308,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
 }
 
 // ----------------------------------------------------------------------------- backward: dK, dV (16 keys per wave)
-template <int HD, int NW>
+template <int HD, int NW, int TRV>
 __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
@@ -359,6 +428,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   };
   StageLane sl;
   sl.init<HD, NW>(head, wave, lane);
+  const unsigned trb = tr_lane_base(smem, lane);
   int pr[2];
   a16_rows<NW>(p, seq0, seqlen, q_begin, wave, lane, pr);
   a16_stage<NW>(rQ, ldq_b, sl, seqlen - (q_begin), pr, smem, wave);
@@ -368,6 +438,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   A16_WAIT_ALL();
   __syncthreads();
 
+#ifdef A32_STAMPS
+  unsigned long long acc_[3] = {0, 0, 0}, last_ = a32::stamp();
+#define A16_STAMP(i) { const unsigned long long t_ = a32::stamp(); acc_[i] += t_ - last_; last_ = t_; }
+#else
+#define A16_STAMP(i)
+#endif
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const int qq0 = q_begin + t * 64;
@@ -378,6 +454,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
       stage_stats(qq0 + 64, buf ^ 1);
       if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
     }
+    A16_STAMP(0)
     const char* sQ = smem + buf * A16_STAGE;
     const char* sDO = sQ + 64 * ROWB;
     const float* sL = stats + buf * 128;
@@ -395,6 +472,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
         for (int s = 1; s < KS; ++s) {
           sa[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sQ, 32 * hq + 16 * jj, s, lane), kf[s], sa[jj], 0, 0, 0);
           dp[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_row(sDO, 32 * hq + 16 * jj, s, lane), vf[s], dp[jj], 0, 0, 0);
+        }
+      }
+      // the transposed dO / Q fragments of this half's dV / dK products: issued here, they land under the exponentials
+      bf16x8_t tq[ND], tdo[ND];
+      if constexpr (TRV != 0) {
+        const unsigned ad = trb + buf * A16_STAGE + hq * 32 * ROWB;
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+          tq[b] = tr_asm<0>(ad ^ (b << 5));
+          tdo[b] = tr_asm<64 * ROWB>(ad ^ (b << 5));
         }
       }
       f32x4_t pa[2];
@@ -422,15 +509,32 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
       }
       const bf16x8_t pf = pack2(pa[0], pa[1]);
       const bf16x8_t df = pack2(sa[0], sa[1]);
+      if constexpr (TRV != 0) {
+        tr_wait();
 #pragma unroll
-      for (int b = 0; b < ND; ++b) {
-        dv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sDO, 32 * hq, b, lane), pf, dv[b], 0, 0, 0);
-        dk[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sQ, 32 * hq, b, lane), df, dk[b], 0, 0, 0);
+        for (int b = 0; b < ND; ++b) {
+          dv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tdo[b], pf, dv[b], 0, 0, 0);
+          dk[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq[b], df, dk[b], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < ND; ++b) {
+          dv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sDO, 32 * hq, b, lane), pf, dv[b], 0, 0, 0);
+          dk[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(sQ, 32 * hq, b, lane), df, dk[b], 0, 0, 0);
+        }
       }
     }
+    A16_STAMP(1)
     A16_WAIT_ALL();
     __syncthreads();
+    A16_STAMP(2)
   }
+#ifdef A32_STAMPS
+  if (p.dbg && lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+    d[0] = acc_[0]; d[1] = acc_[1]; d[2] = acc_[2]; d[3] = (unsigned long long)nt;
+  }
+#endif
   if (!kvalid) return;
   unsigned short* dkrow = p.dk + krow * p.lddk + head * HD;
   unsigned short* dvrow = p.dv + krow * p.lddv + head * HD;
@@ -535,18 +639,42 @@ int fwd_launch(const vm_attn_args* a, hipStream_t st, int variant) {
   }
 }
 
-}  // namespace
-
-#define ATTN_DISPATCH_HD(hd, ...)                         \
-  switch (hd) {                                           \
-    case 128: { constexpr int HD = 128; __VA_ARGS__; break; } \
-    case 112: { constexpr int HD = 112; __VA_ARGS__; break; } \
-    case 96:  { constexpr int HD = 96;  __VA_ARGS__; break; } \
-    case 64:  { constexpr int HD = 64;  __VA_ARGS__; break; } \
-    case 32:  { constexpr int HD = 32;  __VA_ARGS__; break; } \
-    case 16:  { constexpr int HD = 16;  __VA_ARGS__; break; } \
-    default: return VM_ERR_UNSUPPORTED;                   \
+// ---- backward launch: delta (which & 1), dQ (& 2), dK / dV (& 4); variant 0 = transposed reads through the builtin (the round-3
+// kernels, kept for tools/ubench/attn_bench's A/B), 1 = batched through assembly (what ships)
+template <int HD, int TRV>
+int bwd_launch16(const vm_attn_args* a, hipStream_t st, int which) {
+  AttnP p = to_params(a);
+#ifdef A32_STAMPS
+  p.dbg = g_a32_dbg;
+#endif
+  p.n_tiles = (a->max_seqlen + 127) / 128;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    ok = lds_ok((const void*)attn16_dq_k<HD, 8, TRV>, A16_LDS) && lds_ok((const void*)attn16_dkv_k<HD, 8, TRV>, A16_LDS_DKV);
+  });
+  if (!ok) return VM_ERR_LAUNCH;
+  const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
+  if (which & 1) hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, a->n_seq);
+  if (which & 2) hipLaunchKernelGGL((attn16_dq_k<HD, 8, TRV>), grid16(a, 128), dim3(512), A16_LDS, st, p);
+  // dK / dV: two accumulator sets, one 8-wave workgroup per CU
+  if (which & 4) hipLaunchKernelGGL((attn16_dkv_k<HD, 8, TRV>), grid16(a, 128), dim3(512), A16_LDS_DKV, st, p);
+  return VM_OK;
+}
+int bwd_launch(const vm_attn_args* a, hipStream_t st, int variant, int which) {
+  switch (a->head_dim) {
+#ifdef VM_ATTN_BENCH_BUILD
+#define VM_A16_CASE(hd) case hd: return variant ? bwd_launch16<hd, 1>(a, st, which) : bwd_launch16<hd, 0>(a, st, which);
+#else
+#define VM_A16_CASE(hd) case hd: return bwd_launch16<hd, 1>(a, st, which);
+#endif
+    VM_A16_CASE(128) VM_A16_CASE(112) VM_A16_CASE(96) VM_A16_CASE(64) VM_A16_CASE(32) VM_A16_CASE(16)
+#undef VM_A16_CASE
+    default: return VM_ERR_UNSUPPORTED;
   }
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -566,19 +694,11 @@ int vm_attn_bwd_bf16(const vm_attn_args* a, void* stream) {
   if (!args_ok(a) || !a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return VM_ERR_BAD_ARG;
   if (a->lddo % 8 || a->ldo % 8 || a->lddq % 4 || a->lddk % 4 || a->lddv % 4) return VM_ERR_BAD_ARG;
   if (!fits32(a)) return VM_ERR_UNSUPPORTED;
-  AttnP p = to_params(a);
-  const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_ATTN, stream, &tok);
-  p.n_tiles = (a->max_seqlen + 127) / 128;
-    ATTN_DISPATCH_HD(a->head_dim,
-                     if (!lds_ok((const void*)attn16_dq_k<HD, 8>, A16_LDS) || !lds_ok((const void*)attn16_dkv_k<HD, 8>, A16_LDS_DKV)) return VM_ERR_LAUNCH;
-                     hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
-                                        (hipStream_t)stream, p, a->n_seq);
-                     hipLaunchKernelGGL((attn16_dq_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS, (hipStream_t)stream, p);
-                     // dK / dV: 164 VGPRs per wave (two accumulator sets), one 8-wave workgroup per CU
-                     hipLaunchKernelGGL((attn16_dkv_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS_DKV, (hipStream_t)stream, p));
+  const int rc = bwd_launch(a, (hipStream_t)stream, 1, 7);
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 5.0));
+  if (rc != VM_OK) return rc;
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

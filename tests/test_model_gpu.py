@@ -150,6 +150,21 @@ def test_lm_backward_matches_oracle(dev, lm):
     lm.model.vision.transformer.gradient_checkpointing = False
 
 
+def assert_same_grads(a: dict, b: dict):
+    """Bit for bit, except the gradients whose column sums go through fp32 ATOMICS (norm weights / biases: rowwise.hip; ATen's
+    patch-embedding backward): three or more workgroups adding into one address may do so in a different order from launch to launch
+    (seen once in ~10 runs of the suite). The same exception as tests/test_fullsize_gpu.py; anything actually wrong moves these far
+    more than 1e-4."""
+    assert a.keys() == b.keys()
+    atomics = ('norm', 'patch_embedding.')
+    for n in a:
+        if any(t in n for t in atomics):
+            x, y = a[n].float(), b[n].float()
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(x.abs().max()) + 1e-12), n
+        else:
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_checkpointing_does_not_change_gradients(dev, lm):
     lm.train()
     batch, _ = make_inputs(dev, seed=7)
@@ -162,9 +177,7 @@ def test_checkpointing_does_not_change_gradients(dev, lm):
         out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
         out.loss.backward()
         grads.append({n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None})
-    assert grads[0].keys() == grads[1].keys()
-    for n in grads[0]:
-        assert torch.equal(grads[0][n], grads[1][n]), n
+    assert_same_grads(grads[0], grads[1])
     lm.model.gradient_checkpointing = False
     lm.model.vision.transformer.gradient_checkpointing = False
 
@@ -187,8 +200,7 @@ def test_lora_dropout_mask_is_replayed(dev, lm):
         out.loss.backward()
         res.append((out.loss.item(), {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}))
     assert res[0][0] == res[1][0]
-    for n in res[0][1]:
-        assert torch.equal(res[0][1][n], res[1][1][n]), n
+    assert_same_grads(res[0][1], res[1][1])
     for mod in lm.modules():
         if isinstance(mod, Linear) and mod.lora_cfg is not None:
             mod.lora_cfg.lora_dropout = 0.0
@@ -222,8 +234,7 @@ def test_activation_budget_keeps_some_layers_without_changing_gradients(dev, lm)
             got = _grads(lm, batch)
             plans.append(list(ActivationBudget.last_plan))
             assert got[0] == ref[0]
-            for n in ref[1]:
-                assert torch.equal(got[1][n], ref[1][n]), n
+            assert_same_grads(got[1], ref[1])
         assert all(kept == total for total, kept in plans[1]) and len(plans[1]) == 2
         assert sum(kept for _, kept in plans[0]) < sum(kept for _, kept in plans[1])
     finally:
@@ -248,8 +259,7 @@ def test_resident_lora_transposes_match_per_use_transposes(dev, lm):
         assert torch.equal(At, m.A.detach().t()) and torch.equal(Bt, m.B.detach().t())
     got = _grads(lm, batch)
     assert got[0] == ref[0]
-    for n in ref[1]:
-        assert torch.equal(got[1][n], ref[1][n]), n
+    assert_same_grads(got[1], ref[1])
     # an in-place parameter update invalidates the cached copies until the next refresh()
     with torch.no_grad():
         mods[0].A.mul_(1.5)
@@ -336,9 +346,7 @@ def test_side_stream_factor_gradients_match_main_stream(dev, lm):
     for n in plain:
         assert rel(res[0][n].float(), plain[n].float()) < 2e-3, (n, rel(res[0][n].float(), plain[n].float()))
     for other in res[1:]:
-        assert other.keys() == res[0].keys()
-        for n in res[0]:
-            assert torch.equal(res[0][n], other[n]), n
+        assert_same_grads(res[0], other)
 
 
 def test_lm_head_on_labelled_rows_equals_the_full_product(dev):

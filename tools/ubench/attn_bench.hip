@@ -1,7 +1,16 @@
 // Stand-alone A/B bench + check of the bf16 attention kernels (no torch): includes the library's translation unit, so the
 // kernels timed here are the ones that ship. Variants are interleaved in ONE process (guide rule 24), random data (rule 25).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVM_KEEP_DENORMS tools/ubench/attn_bench.hip -o tools/ubench/attn_bench
-//   tools/ubench/attn_bench [rounds]
+//   tools/ubench/attn_bench [rounds] [shape] [forward variant]
+// Backward: the round-3 kernels (transposed reads through the builtin, variant 0) against the shipped ones (batched through assembly, 1):
+// dQ / dK / dV must agree bit for bit (same MFMA order), dQ and dK/dV are timed separately.
+#define VM_ATTN_BENCH_BUILD 1
+#ifndef BV0
+#define BV0 0          // backward A/B: variants BV0 and BV1 (0 = transposed reads through the builtin, 1 = assembly batches)
+#endif
+#ifndef BV1
+#define BV1 1
+#endif
 #include "../../mmmm_amd/csrc/attn_bf16.hip"
 #include <algorithm>
 #include <cmath>
@@ -61,6 +70,7 @@ int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 10;
   const int only_shape = argc > 2 ? atoi(argv[2]) : -1;          // run one shape / one variant (profiler passes)
   const int only_variant = argc > 3 ? atoi(argv[3]) : -1;
+  const int stress = argc > 4 ? atoi(argv[4]) : 0;                 // determinism stress: that many extra forward + backward launches, each compared bit for bit
   std::vector<Shape> shapes = {
     {"vit-e 8x785 h16 d112", std::vector<int>(8, 785), 16, 112, 0},
     {"decoder 8x456 h32 d128 causal", std::vector<int>(8, 456), 32, 128, 1},
@@ -175,6 +185,86 @@ int main(int argc, char** argv) {
       std::sort(times[vi].begin(), times[vi].end());
       const float med = times[vi][times[vi].size() / 2], mn = times[vi][0];
       printf("  variant %2d: fwd median %7.1f us (min %7.1f)  %6.0f TFLOP/s\n", variants[vi], med, mn, flops / (med * 1e-6) / 1e12);
+    }
+    {
+      unsigned short *ddo, *dgrad[2];
+      float* ddelta;
+      const size_t no = (size_t)rows * H * hd;
+      std::vector<unsigned short> hdo(no);
+      for (auto& x : hdo) x = f2bf_host(gauss());
+      CK(hipMalloc(&ddo, no * 2)); CK(hipMalloc(&ddelta, (size_t)H * rows * 4));
+      CK(hipMemcpy(ddo, hdo.data(), no * 2, hipMemcpyHostToDevice));
+      for (int v = 0; v < 2; ++v) CK(hipMalloc(&dgrad[v], hq.size() * 2));
+      fwd_launch(&a, 0, 8);
+      a.dout = ddo; a.lddo = H * hd; a.delta = ddelta; a.lddq = a.lddk = a.lddv = ld;
+      std::vector<unsigned short> hg[2];
+      for (int v = 0; v < 2; ++v) {
+        CK(hipMemset(dgrad[v], 0, hq.size() * 2));
+        a.dq = dgrad[v]; a.dk = dgrad[v] + H * hd; a.dv = dgrad[v] + 2 * H * hd;
+        const int rc = bwd_launch(&a, 0, (v ? BV1 : BV0), 7);
+        if (rc != VM_OK) { printf("  bwd variant %d: rc %d\n", v, rc); return 1; }
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { printf("  bwd variant %d: launch failed: %s\n", v, hipGetErrorString(e)); return 1; }
+        hg[v].resize(hq.size());
+        CK(hipMemcpy(hg[v].data(), dgrad[v], hq.size() * 2, hipMemcpyDeviceToHost));
+      }
+      size_t diff = 0; double nrm = 0;
+      for (size_t i = 0; i < hq.size(); ++i) { diff += hg[0][i] != hg[1][i]; nrm += std::fabs(bf2f_host(hg[1][i])); }
+      printf("  bwd: variant B vs A: %zu of %zu gradient elements differ (mean |g| %.3e) %s\n", diff, hq.size(), nrm / hq.size(), diff ? "**** MISMATCH ****" : "OK");
+      if (stress > 0) {
+        std::vector<unsigned short> ho0(no), ho1(no), hg1(hq.size());
+        CK(hipMemcpy(ho0.data(), dout, no * 2, hipMemcpyDeviceToHost));
+        size_t bad_f = 0, bad_b = 0;
+        a.dq = dgrad[1]; a.dk = dgrad[1] + H * hd; a.dv = dgrad[1] + 2 * H * hd;
+        for (int i = 0; i < stress; ++i) {
+          CK(hipMemset(dout, 0xFF, no * 2)); CK(hipMemset(dgrad[1], 0xFF, hq.size() * 2));
+          fwd_launch(&a, 0, 8);
+          bwd_launch(&a, 0, BV1, 7);
+          CK(hipDeviceSynchronize());
+          CK(hipMemcpy(ho1.data(), dout, no * 2, hipMemcpyDeviceToHost));
+          CK(hipMemcpy(hg1.data(), dgrad[1], hq.size() * 2, hipMemcpyDeviceToHost));
+          bad_f += std::memcmp(ho0.data(), ho1.data(), no * 2) != 0;
+          bad_b += std::memcmp(hg[1].data(), hg1.data(), hq.size() * 2) != 0;
+        }
+        printf("  stress: %d launches, forward differed %zu times, backward %zu times %s\n", stress, bad_f, bad_b, (bad_f || bad_b) ? "**** NONDETERMINISTIC ****" : "OK");
+      }
+      for (int which = 2; which <= 4; which += 2) {
+        std::vector<float> tv[2];
+        for (int r = 0; r < rounds; ++r)
+          for (int v = 0; v < 2; ++v) {
+            a.dq = dgrad[v]; a.dk = dgrad[v] + H * hd; a.dv = dgrad[v] + 2 * H * hd;
+            const int reps = 5;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) bwd_launch(&a, 0, (v ? BV1 : BV0), which);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) tv[v].push_back(ms / reps * 1e3f);
+          }
+        for (int v = 0; v < 2; ++v) {
+          if (tv[v].empty()) continue;
+          std::sort(tv[v].begin(), tv[v].end());
+          printf("  bwd %s variant %d: median %7.1f us (min %7.1f)\n", which == 2 ? "dQ   " : "dK/dV", (v ? BV1 : BV0), tv[v][tv[v].size() / 2], tv[v][0]);
+        }
+      }
+#ifdef A32_STAMPS
+      for (int v = 0; v < 2; ++v) {
+        const int nb = 8 * ((H * n_seq + 7) / 8) * ((maxlen + 127) / 128);
+        unsigned long long* dbg;
+        CK(hipMalloc(&dbg, (size_t)nb * 8 * 4 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 8 * 4 * 8));
+        g_a32_dbg = dbg;
+        bwd_launch(&a, 0, (v ? BV1 : BV0), 4);
+        CK(hipDeviceSynchronize());
+        g_a32_dbg = nullptr;
+        std::vector<unsigned long long> hd_((size_t)nb * 8 * 4);
+        CK(hipMemcpy(hd_.data(), dbg, hd_.size() * 8, hipMemcpyDeviceToHost));
+        double sm[3] = {0, 0, 0}, tl = 0;
+        for (size_t i = 0; i < hd_.size(); i += 4) { if (!hd_[i + 3]) continue; for (int k = 0; k < 3; ++k) sm[k] += (double)hd_[i + k]; tl += (double)hd_[i + 3]; }
+        printf("  bwd dK/dV variant %d stamps per tile: issue %.0f  compute %.0f  wait+barrier %.0f\n", (v ? BV1 : BV0), sm[0] / tl, sm[1] / tl, sm[2] / tl);
+        CK(hipFree(dbg));
+      }
+#endif
+      CK(hipFree(ddo)); CK(hipFree(ddelta)); CK(hipFree(dgrad[0])); CK(hipFree(dgrad[1]));
     }
     CK(hipFree(dqkv)); CK(hipFree(dout)); CK(hipFree(dlse)); CK(hipFree(dref)); CK(hipFree(dlse_ref)); CK(hipFree(dcu));
   }
