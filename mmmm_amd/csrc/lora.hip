@@ -717,6 +717,7 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
   };
   const bool drop = q.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(q.drop_p);
+  const TrLane trl = tr_lane(smem, lane);
 #pragma unroll
   for (int i = 0; i < GR_STAGES - 1; ++i) stage(i, i);
   for (int st = 0; st < steps; ++st) {
@@ -726,7 +727,6 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
     __syncthreads();                                        // ... everybody's has, and step st-1 has been consumed
     stage(st + GR_STAGES - 1, (buf + GR_STAGES - 1) % GR_STAGES);
     char* sw = smem + buf * GR_STAGE_BYTES;
-    const char* ss = sw + 2 * 32 * ROWB;
     if (drop) {
       const int r0 = rb + st * 32;
 #pragma unroll
@@ -741,20 +741,30 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
         vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
         *reinterpret_cast<u16x8_t*>(addr) = v;
       }
-      __syncthreads();
+      // (not __syncthreads(): its fence would drain the DMA of the next step that was issued above)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    const char* swv = sw + (wave >> 1) * 32 * ROWB;        // the 128-column sub-tile that holds this wave's 64 columns
-    const int cb = 2 * (wave & 1);                         // ... as 32-column blocks cb, cb + 1 of it
+    // the step's eight transposed fragments as one batch of assembly reads (vm_tile.hpp: the builtin form makes hipcc wait for the
+    // DMA issued above before the first read, i.e. nothing of the next step's flight would overlap these MFMAs)
+    const unsigned o = buf * GR_STAGE_BYTES;
+    const unsigned sA = trl.a + o + 2 * 32 * ROWB, sB = trl.b + o + 2 * 32 * ROWB;                    // S
+    const unsigned wA = (trl.a + o + (wave >> 1) * 32 * ROWB) ^ ((wave & 1) << 7);                     // the wave's 128-column sub-tile,
+    const unsigned wB = (trl.b + o + (wave >> 1) * 32 * ROWB) ^ ((wave & 1) << 7);                     // 32-column blocks 2 (wave & 1) + 0 / 1
+    bf16x8_t sf[2][2], wf[2][2];
+    sf[0][0] = tr_asm2<0>(sA, sB);                 sf[0][1] = tr_asm2<0>(sA ^ 64, sB ^ 64);
+    wf[0][0] = tr_asm2<0>(wA, wB);                 wf[0][1] = tr_asm2<0>(wA ^ 64, wB ^ 64);
+    sf[1][0] = tr_asm2<16 * ROWB>(sA, sB);         sf[1][1] = tr_asm2<16 * ROWB>(sA ^ 64, sB ^ 64);
+    wf[1][0] = tr_asm2<16 * ROWB>(wA, wB);         wf[1][1] = tr_asm2<16 * ROWB>(wA ^ 64, wB ^ 64);
+    tr_asm_wait();
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8_t s0 = frag_tr(ss, 16 * ks, 0, lane), s1 = frag_tr(ss, 16 * ks, 1, lane);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const bf16x8_t wa = frag_tr(swv, 16 * ks, cb + a, lane);
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, s0, acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, s1, acc[a][1], 0, 0, 0);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][a], sf[ks][0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][a], sf[ks][1], acc[a][1], 0, 0, 0);
       }
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-row tail stages before the LDS is reused
   __syncthreads();
