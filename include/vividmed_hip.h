@@ -414,9 +414,13 @@ typedef struct vm_attn_args {
   const void* dout; int64_t lddo;
   void* dq; void* dk; void* dv; int64_t lddq, lddk, lddv;
   float* delta;            /* [H, total_pos] scratch: rowsum(dO*O) */
+  /* backward, optional: device scratch of vm_attn_bwd_workspace_bytes() bytes. With it the dK/dV kernel leaves dS^T (bf16, the operand
+   * of its own dK product) behind and dQ = dS K is a plain product over it; without it (NULL / too small) dQ recomputes S and dP. */
+  void* workspace; int64_t workspace_bytes;
 } vm_attn_args;
 int vm_attn_fwd_bf16(const vm_attn_args* args_host, void* stream);
 int vm_attn_bwd_bf16(const vm_attn_args* args_host, void* stream);
+int vm_attn_bwd_workspace_bytes(const vm_attn_args* args_host, int64_t* bytes_out);
 
 /* Trilinear up-sampling of fp32 volumes, F.interpolate(x, size, mode='trilinear', align_corners=False) as used on the mask
  * logits in Sam._predict_masks (segvol/modeling/sam.py:57-87). x [n, di, hi, wi] -> y [n, dout, ho, wo] (n = prompts x channels).

@@ -47,6 +47,7 @@ struct AttnP {
   const unsigned short* dout; int64_t lddo;
   unsigned short* dq; unsigned short* dk; unsigned short* dv; int64_t lddq, lddk, lddv;
   float* delta;
+  unsigned short* ds; int ds_pitch;   // backward with a workspace: dS^T [head][position of the key][query position, pitch ds_pitch] bf16, or null
   unsigned long long* dbg;   // diagnostic builds only (-DA32_STAMPS)
 };
 
@@ -376,8 +377,97 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
   }
 }
 
+// ----------------------------------------------------------------------------- backward: dQ = dS K from the stored dS^T (16 queries per wave)
+// Same blocks, staging and epilogue as attn16_dq_k; per 64-key tile the K tile and the [64 keys x 128 query positions] tile of dS^T come in by
+// LDS-DMA and a wave's work is 2 (ND + 1) transposed fragments and 2 ND MFMAs (the recomputing kernel: 32 + 2 ND MFMAs, 32 row fragments, the
+// exponentials). The transposed read of the dS^T tile at the wave's 16-query column block IS the operand the recomputing kernel packs in registers.
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn16_dq_ds_k(const AttnP p) {
+  constexpr int QB = NW * 16;
+  constexpr int ND = HD / 16;
+  constexpr int PW = 16 / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ln = lane & 15, g = lane >> 4;
+  int tile_, head, seq;
+  if (!a16_block(p, tile_, head, seq)) return;
+  const int seq0 = p.cu[seq];
+  const int seqlen = p.cu[seq + 1] - seq0;
+  const int q0 = tile_ * QB;
+  if (q0 >= seqlen) return;
+  const int qpos = q0 + wave * 16 + ln;
+  const bool qvalid = qpos < seqlen;
+  const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
+  f32x4_t dq[ND];
+#pragma unroll
+  for (int b = 0; b < ND; ++b) dq[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int kv_end = p.causal ? min(seqlen, q0 + QB) : seqlen;
+  const int nt = (kv_end + 63) / 64;
+  const __amdgpu_buffer_rsrc_t rK = whole_rsrc(p.k);
+  const __amdgpu_buffer_rsrc_t rS = whole_rsrc(p.ds + ((int64_t)head * p.total_pos_max + seq0) * p.ds_pitch);
+  const int ldk_b = (int)p.ldk * 2, lds_b = p.ds_pitch * 2;
+  StageLane sl;
+  sl.init<HD, NW>(head, wave, lane);
+  int srow[PW], scol[PW];                        // dS^T tile: the lane's tile row and its source byte column (query positions q0 ..)
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    srow[i] = (wave * PW + i) * 4 + (lane >> 4);
+    scol[i] = q0 * 2 + (((lane & 15) ^ swz16(srow[i])) << 4);
+  }
+  auto stage_ds = [&](int kv0, char* tile) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int key = kv0 + srow[i];
+      const int voff = key < seqlen ? (int)__umul24(key, lds_b) + scol[i] : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (lds_vptr_t)(tile + (wave * PW + i) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  const unsigned trb = tr_lane_base(smem, lane);
+  int pr[2];
+  a16_rows<NW>(p, seq0, seqlen, 0, wave, lane, pr);
+  a16_stage<NW>(rK, ldk_b, sl, seqlen - (0), pr, smem, wave);
+  stage_ds(0, smem + 64 * ROWB);
+  if (nt > 1) a16_rows<NW>(p, seq0, seqlen, 64, wave, lane, pr);
+  A16_WAIT_ALL();
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) {
+      char* nb = smem + (buf ^ 1) * A16_STAGE;
+      a16_stage<NW>(rK, ldk_b, sl, seqlen - ((t + 1) * 64), pr, nb, wave);
+      stage_ds((t + 1) * 64, nb + 64 * ROWB);
+      if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
+    }
+    bf16x8_t tk[2][ND], td[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const unsigned ad = trb + buf * A16_STAGE + c * 32 * ROWB;
+      td[c] = tr_asm<64 * ROWB>(ad ^ (wave << 5));
+#pragma unroll
+      for (int b = 0; b < ND; ++b) tk[c][b] = tr_asm<0>(ad ^ (b << 5));
+    }
+    tr_wait();
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int b = 0; b < ND; ++b) dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[c][b], td[c], dq[b], 0, 0, 0);
+    A16_WAIT_ALL();
+    __syncthreads();
+  }
+  if (!qvalid) return;
+  unsigned short* drow = p.dq + qrow * p.lddq + head * HD;
+#pragma unroll
+  for (int b = 0; b < ND; ++b) {
+    const u16x4_t w = {f2bf(dq[b][0] * p.scale), f2bf(dq[b][1] * p.scale), f2bf(dq[b][2] * p.scale), f2bf(dq[b][3] * p.scale)};
+    *reinterpret_cast<u16x4_t*>(drow + 16 * b + 4 * g) = w;
+  }
+}
+
 // ----------------------------------------------------------------------------- backward: dK, dV (16 keys per wave)
-template <int HD, int NW, int TRV>
+// DS: the kernel also writes dS^T = P^T ∘ (dP^T − delta) (bf16, exactly the operand of its own dK product) to the workspace, one row of
+// query positions per key: dQ = dS K is then a plain product over it (attn16_dq_ds_k) instead of a second recomputation of S and dP.
+template <int HD, int NW, int TRV, bool DS = false>
 __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   constexpr int QB = NW * 16;
   constexpr int KS = (HD + 31) / 32;
@@ -429,6 +519,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   StageLane sl;
   sl.init<HD, NW>(head, wave, lane);
   const unsigned trb = tr_lane_base(smem, lane);
+  // dS^T rows of this (head, sequence): the lane's key row, 4 consecutive query positions per store (an invalid key stores out of bounds:
+  // the store count per tile stays wave-uniform for the counted wait below)
+  __amdgpu_buffer_rsrc_t rDS = rQ;
+  int ds_off = OOB_OFF;
+  if constexpr (DS) {
+    rDS = whole_rsrc(p.ds + ((int64_t)head * p.total_pos_max + seq0) * p.ds_pitch);
+    if (kvalid) ds_off = (kpos * p.ds_pitch + 4 * g) * 2;
+  }
   int pr[2];
   a16_rows<NW>(p, seq0, seqlen, q_begin, wave, lane, pr);
   a16_stage<NW>(rQ, ldq_b, sl, seqlen - (q_begin), pr, smem, wave);
@@ -509,6 +607,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
       }
       const bf16x8_t pf = pack2(pa[0], pa[1]);
       const bf16x8_t df = pack2(sa[0], sa[1]);
+      if constexpr (DS) {
+        typedef int i32x2_t __attribute__((ext_vector_type(2)));
+        const i32x4_t d4 = __builtin_bit_cast(i32x4_t, df);
+        const int o = kvalid ? ds_off + (qq0 + 32 * hq) * 2 : OOB_OFF;
+        __builtin_amdgcn_raw_buffer_store_b64((i32x2_t){d4[0], d4[1]}, rDS, o, 0, 0);                       // q = qq0 + 32 hq + 4 g + 0..3
+        __builtin_amdgcn_raw_buffer_store_b64((i32x2_t){d4[2], d4[3]}, rDS, kvalid ? o + 32 : OOB_OFF, 0, 0);   // ... + 16
+      }
       if constexpr (TRV != 0) {
         tr_wait();
 #pragma unroll
@@ -525,8 +630,16 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
       }
     }
     A16_STAMP(1)
-    A16_WAIT_ALL();
-    __syncthreads();
+    if constexpr (DS) {
+      // the tile's four dS^T stores are this wave's youngest memory operations: everything older — the next tile's DMA — has landed at
+      // vmcnt(4), and the stores keep flying (vmcnt counts stores on gfx950; __syncthreads() would drain them with its fence)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      A16_WAIT_ALL();
+      __syncthreads();
+    }
     A16_STAMP(2)
   }
 #ifdef A32_STAMPS
@@ -560,6 +673,7 @@ AttnP to_params(const vm_attn_args* a) {
   p.dq = (unsigned short*)a->dq; p.dk = (unsigned short*)a->dk; p.dv = (unsigned short*)a->dv;
   p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
   p.delta = a->delta;
+  p.ds = nullptr; p.ds_pitch = 0;
   p.dbg = nullptr;
   return p;
 }
@@ -641,6 +755,10 @@ int fwd_launch(const vm_attn_args* a, hipStream_t st, int variant) {
 
 // ---- backward launch: delta (which & 1), dQ (& 2), dK / dV (& 4); variant 0 = transposed reads through the builtin (the round-3
 // kernels, kept for tools/ubench/attn_bench's A/B), 1 = batched through assembly (what ships)
+// bytes of the dS^T workspace: [head][position][query position, pitch = max_seqlen rounded up to the 128-query block] bf16
+int64_t bwd_ds_pitch(const vm_attn_args* a) { return ((int64_t)a->max_seqlen + 127) / 128 * 128; }
+int64_t bwd_ds_bytes(const vm_attn_args* a) { return (int64_t)a->n_heads * a->total_pos_max * bwd_ds_pitch(a) * 2; }
+
 template <int HD, int TRV>
 int bwd_launch16(const vm_attn_args* a, hipStream_t st, int which) {
   AttnP p = to_params(a);
@@ -651,11 +769,21 @@ int bwd_launch16(const vm_attn_args* a, hipStream_t st, int which) {
   static std::once_flag once;
   static bool ok = false;
   std::call_once(once, [] {
-    ok = lds_ok((const void*)attn16_dq_k<HD, 8, TRV>, A16_LDS) && lds_ok((const void*)attn16_dkv_k<HD, 8, TRV>, A16_LDS_DKV);
+    ok = lds_ok((const void*)attn16_dq_k<HD, 8, TRV>, A16_LDS) && lds_ok((const void*)attn16_dkv_k<HD, 8, TRV>, A16_LDS_DKV) &&
+         lds_ok((const void*)attn16_dkv_k<HD, 8, TRV, true>, A16_LDS_DKV) && lds_ok((const void*)attn16_dq_ds_k<HD, 8>, A16_LDS);
   });
   if (!ok) return VM_ERR_LAUNCH;
   const int64_t items = (int64_t)a->total_pos_max;     // delta: one wave per position
   if (which & 1) hipLaunchKernelGGL(attn_delta_k<HD>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p, a->n_seq);
+  // With a workspace (TRV != 0; one sequence's rows must stay inside 32-bit byte offsets): dK / dV first — it leaves dS^T behind — then dQ as a
+  // product over it. Without: dQ and dK / dV each recompute S and dP.
+  const bool ds = TRV != 0 && a->workspace && a->workspace_bytes >= bwd_ds_bytes(a) && (int64_t)a->max_seqlen * bwd_ds_pitch(a) * 2 < OOB_OFF;
+  if (ds) {
+    p.ds = (unsigned short*)a->workspace; p.ds_pitch = (int)bwd_ds_pitch(a);
+    if (which & 4) hipLaunchKernelGGL((attn16_dkv_k<HD, 8, TRV, true>), grid16(a, 128), dim3(512), A16_LDS_DKV, st, p);
+    if (which & 2) hipLaunchKernelGGL((attn16_dq_ds_k<HD, 8>), grid16(a, 128), dim3(512), A16_LDS, st, p);
+    return VM_OK;
+  }
   if (which & 2) hipLaunchKernelGGL((attn16_dq_k<HD, 8, TRV>), grid16(a, 128), dim3(512), A16_LDS, st, p);
   // dK / dV: two accumulator sets, one 8-wave workgroup per CU
   if (which & 4) hipLaunchKernelGGL((attn16_dkv_k<HD, 8, TRV>), grid16(a, 128), dim3(512), A16_LDS_DKV, st, p);
@@ -687,6 +815,12 @@ int vm_attn_fwd_bf16(const vm_attn_args* a, void* stream) {
   vm_prof_end_(VM_PROF_ATTN, stream, tok, attn_flops(a, 2.0));
   if (rc != VM_OK) return rc;
   VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_attn_bwd_workspace_bytes(const vm_attn_args* a, int64_t* bytes) {
+  if (!a || !bytes || a->n_heads <= 0 || a->total_pos_max <= 0 || a->max_seqlen <= 0) return VM_ERR_BAD_ARG;
+  *bytes = bwd_ds_bytes(a);
   return VM_OK;
 }
 

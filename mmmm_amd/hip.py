@@ -64,6 +64,7 @@ class AttnArgs(C.Structure):
         ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p),
         ('lddq', C.c_int64), ('lddk', C.c_int64), ('lddv', C.c_int64),
         ('delta', C.c_void_p),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
     ]
 
 

@@ -642,6 +642,28 @@ def test_attention_bf16_row_indirection(dev, K):
     assert torch.equal(g_phys[perm], g_seq)
 
 
+@pytest.mark.parametrize('hd,H,causal,lens', [(112, 2, False, [785, 33]), (128, 2, True, [456, 130, 1, 64]), (64, 3, False, [200]), (16, 1, True, [129])])
+def test_attention_backward_workspace_path_equals_recompute_path(dev, K, monkeypatch, hd, H, causal, lens):
+    """with the dS^T scratch (vm_attn_bwd_workspace_bytes) dK / dV stores dS^T and dQ is a product over it; without it dQ recomputes
+    S and dP. Same bf16 dS, same key order of the dQ sum: the two must agree bit for bit — ragged lengths, the causal mask, row indirection"""
+    cu = [0]
+    for l in lens:
+        cu.append(cu[-1] + l)
+    rows = cu[-1]
+    qkv = torch.randn(rows, 3 * H * hd, device=dev).bfloat16()
+    sl = lambda t: (t[:, :H * hd], t[:, H * hd:2 * H * hd], t[:, 2 * H * hd:])
+    cu_t = torch.tensor(cu, dtype=torch.int32, device=dev)
+    perm = torch.randperm(rows, device=dev).int()
+    dout = torch.randn(rows, H * hd, device=dev).bfloat16()
+    for rop in (None, perm):
+        out, lse = K.attn_fwd(*sl(qkv), cu_t, max(lens), H, hd, hd ** -0.5, causal, row_of_pos=rop)
+        monkeypatch.setattr(K, 'ATTN_DS_MAX_BYTES', 1 << 30)
+        g_ws = K.attn_bwd(*sl(qkv), out, lse, dout, cu_t, max(lens), H, hd, hd ** -0.5, causal, row_of_pos=rop)
+        monkeypatch.setattr(K, 'ATTN_DS_MAX_BYTES', 0)
+        g_re = K.attn_bwd(*sl(qkv), out, lse, dout, cu_t, max(lens), H, hd, hd ** -0.5, causal, row_of_pos=rop)
+        assert torch.equal(g_ws, g_re)
+
+
 def test_attention_rare_rescale_branch(dev, K):
     # spike one key late in the sequence so the running max jumps in a later tile (guide rule 26)
     H, hd, L = 1, 128, 256

@@ -6,10 +6,10 @@
 // dQ / dK / dV must agree bit for bit (same MFMA order), dQ and dK/dV are timed separately.
 #define VM_ATTN_BENCH_BUILD 1
 #ifndef BV0
-#define BV0 0          // backward A/B: variants BV0 and BV1 (0 = transposed reads through the builtin, 1 = assembly batches)
+#define BV0 1          // backward A/B: variants BV0 and BV1 (0 = transposed reads through the builtin, 1 = assembly batches, 2 = 1 + the dS^T workspace)
 #endif
 #ifndef BV1
-#define BV1 1
+#define BV1 2
 #endif
 #include "../../mmmm_amd/csrc/attn_bf16.hip"
 #include <algorithm>
@@ -195,22 +195,34 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&ddo, no * 2)); CK(hipMalloc(&ddelta, (size_t)H * rows * 4));
       CK(hipMemcpy(ddo, hdo.data(), no * 2, hipMemcpyHostToDevice));
       for (int v = 0; v < 2; ++v) CK(hipMalloc(&dgrad[v], hq.size() * 2));
+      void* dws = nullptr;
+      const int64_t ws_bytes = bwd_ds_bytes(&a);
+      CK(hipMalloc(&dws, (size_t)ws_bytes));
+      auto bwd = [&](int variant, int which) {
+        a.workspace = variant == 2 ? dws : nullptr; a.workspace_bytes = variant == 2 ? ws_bytes : 0;
+        return bwd_launch(&a, 0, variant == 2 ? 1 : variant, which);
+      };
       fwd_launch(&a, 0, 8);
       a.dout = ddo; a.lddo = H * hd; a.delta = ddelta; a.lddq = a.lddk = a.lddv = ld;
       std::vector<unsigned short> hg[2];
       for (int v = 0; v < 2; ++v) {
         CK(hipMemset(dgrad[v], 0, hq.size() * 2));
         a.dq = dgrad[v]; a.dk = dgrad[v] + H * hd; a.dv = dgrad[v] + 2 * H * hd;
-        const int rc = bwd_launch(&a, 0, (v ? BV1 : BV0), 7);
+        const int rc = bwd((v ? BV1 : BV0), 7);
         if (rc != VM_OK) { printf("  bwd variant %d: rc %d\n", v, rc); return 1; }
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { printf("  bwd variant %d: launch failed: %s\n", v, hipGetErrorString(e)); return 1; }
         hg[v].resize(hq.size());
         CK(hipMemcpy(hg[v].data(), dgrad[v], hq.size() * 2, hipMemcpyDeviceToHost));
       }
-      size_t diff = 0; double nrm = 0;
-      for (size_t i = 0; i < hq.size(); ++i) { diff += hg[0][i] != hg[1][i]; nrm += std::fabs(bf2f_host(hg[1][i])); }
-      printf("  bwd: variant B vs A: %zu of %zu gradient elements differ (mean |g| %.3e) %s\n", diff, hq.size(), nrm / hq.size(), diff ? "**** MISMATCH ****" : "OK");
+      size_t diff = 0; double nrm = 0, num = 0, den = 0;
+      for (size_t i = 0; i < hq.size(); ++i) {
+        const double x = bf2f_host(hg[0][i]), y = bf2f_host(hg[1][i]);
+        diff += hg[0][i] != hg[1][i]; nrm += std::fabs(y); num += (x - y) * (x - y); den += x * x;
+      }
+      // (variants 0 / 1 are bit-identical; the workspace form sums dQ over the same bf16 dS in the same key order: identical as well)
+      printf("  bwd: variant %d vs %d: %zu of %zu gradient elements differ, rel L2 %.2e (mean |g| %.3e) %s\n", BV1, BV0, diff, hq.size(), std::sqrt(num / std::max(den, 1e-30)),
+             nrm / hq.size(), std::sqrt(num / std::max(den, 1e-30)) > 1e-3 ? "**** MISMATCH ****" : "OK");
       if (stress > 0) {
         std::vector<unsigned short> ho0(no), ho1(no), hg1(hq.size());
         CK(hipMemcpy(ho0.data(), dout, no * 2, hipMemcpyDeviceToHost));
@@ -219,7 +231,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < stress; ++i) {
           CK(hipMemset(dout, 0xFF, no * 2)); CK(hipMemset(dgrad[1], 0xFF, hq.size() * 2));
           fwd_launch(&a, 0, 8);
-          bwd_launch(&a, 0, BV1, 7);
+          bwd(BV1, 7);
           CK(hipDeviceSynchronize());
           CK(hipMemcpy(ho1.data(), dout, no * 2, hipMemcpyDeviceToHost));
           CK(hipMemcpy(hg1.data(), dgrad[1], hq.size() * 2, hipMemcpyDeviceToHost));
@@ -235,7 +247,7 @@ int main(int argc, char** argv) {
             a.dq = dgrad[v]; a.dk = dgrad[v] + H * hd; a.dv = dgrad[v] + 2 * H * hd;
             const int reps = 5;
             CK(hipEventRecord(e0));
-            for (int i = 0; i < reps; ++i) bwd_launch(&a, 0, (v ? BV1 : BV0), which);
+            for (int i = 0; i < reps; ++i) bwd((v ? BV1 : BV0), which);
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -253,7 +265,7 @@ int main(int argc, char** argv) {
         unsigned long long* dbg;
         CK(hipMalloc(&dbg, (size_t)nb * 8 * 4 * 8)); CK(hipMemset(dbg, 0, (size_t)nb * 8 * 4 * 8));
         g_a32_dbg = dbg;
-        bwd_launch(&a, 0, (v ? BV1 : BV0), 4);
+        bwd((v ? BV1 : BV0), 4);
         CK(hipDeviceSynchronize());
         g_a32_dbg = nullptr;
         std::vector<unsigned long long> hd_((size_t)nb * 8 * 4);
@@ -264,6 +276,7 @@ int main(int argc, char** argv) {
         CK(hipFree(dbg));
       }
 #endif
+      CK(hipFree(dws));
       CK(hipFree(ddo)); CK(hipFree(ddelta)); CK(hipFree(dgrad[0])); CK(hipFree(dgrad[1]));
     }
     CK(hipFree(dqkv)); CK(hipFree(dout)); CK(hipFree(dlse)); CK(hipFree(dref)); CK(hipFree(dlse_ref)); CK(hipFree(dcu));
