@@ -306,6 +306,147 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------ fp32 operands, split ONCE per element while staging
+// gemm_nt_k<4, ., ., NS> stages raw fp32 tiles by LDS-DMA and every wave splits the fragments it reads: the activation rows are
+// shared by the 4 (64-row tile) or 2 (128-row tile) waves of a row, so the split of one element runs up to 4 times and the loop is
+// VALU-bound (64-row tile, NS = 2: ~140 vector instructions against 24 MFMAs per K-tile). Here a K-tile goes global -> registers ->
+// split_f32x8 -> NS bf16 planes in LDS (one split per element: 3 fragments per thread), and the waves read bf16 operand fragments.
+// Same terms, same products, same order as the in-register form: bit-identical results. No LoRA extension (K2 = 0: the fp32 islands
+// have none). Plane image: 16-row blocks of 1 KiB, row r of a block at 64 r, its 16-byte chunk k (8 consecutive K) at slot
+// (k + 2 (r >> 2)) & 3 — the four 16-lane groups of a ds_read_b128 each touch 16 distinct slots of the 256-byte bank row.
+template <int BMT, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32p_k(const GemmParams p) {
+  constexpr int NI = BMT == 128 ? 4 : 2;
+  constexpr int UA = BMT / 64;                           // staging units (row, 8 K) per thread: activation; the weight tile has 2
+  constexpr int A_PLANE = BMT * 64, B_PLANE = BN * 64;
+  constexpr int STAGE = NS * (A_PLANE + B_PLANE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 * STAGE
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = BMT == 128 ? wave >> 1 : 0, wn = BMT == 128 ? wave & 1 : wave;
+  int tm, tn;
+  gemm_tile_id(p, tm, tn);
+  int row0, nrows, seg;
+  gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
+  if (nrows <= 0) return;
+  const int n0 = tn * BN;
+  const int ncols = min(BN, p.N - n0);
+  const char* Bw = seg ? p.B1 : p.B0;
+  const int lda_b = (int)p.lda * 4, ldb_b = (int)p.ldb * 4;
+  const int kbeg = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
+  const int kloc = p.ksplit > 1 ? min(p.kchunk, p.K - kbeg) : p.K;
+  const int kskip = kbeg * 4;
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b + kskip, nrows * lda_b - kskip);
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b + kskip, ncols * ldb_b - kskip);
+  const int kt_total = kloc / 32;
+
+  f32x4_t acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int urow = tid >> 2, uk = tid & 3;
+  auto plane_off = [](int row, int k) { return (row >> 4) * 1024 + (row & 15) * 64 + (((k + 2 * ((row & 15) >> 2)) & 3) << 4); };
+  // (Two K-tiles of loads in flight were tried — the memory latency is ~8 K-tiles of MFMA work — and changed nothing: 61 vs 62 us on
+  // [3136 x 3072 x 768]. What bounds these launches is operand traffic: 64 x 128 tiles of fp32 operands are 21 flop per byte, the
+  // 1 176 workgroups of that shape pull 693 MB through the L2s, 11 TB/s at the measured time.)
+  f32x4_t ga[UA][2], gb[2][2];
+  auto load = [&](int t) {
+    const int koff = t * 128;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int voff = (urow + 64 * u) * lda_b + uk * 32;
+      ga[u][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, koff, 0));
+      ga[u][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rA, voff + 16, koff, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int voff = (urow + 64 * u) * ldb_b + uk * 32;
+      gb[u][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rB, voff, koff, 0));
+      gb[u][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rB, voff + 16, koff, 0));
+    }
+  };
+  auto split_write = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + NS * A_PLANE;
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      bf16x8_t t[NS];
+      split_f32x8<NS>(ga[u][0], ga[u][1], t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x8_t*>(sa + s * A_PLANE + plane_off(urow + 64 * u, uk)) = t[s];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8_t t[NS];
+      split_f32x8<NS>(gb[u][0], gb[u][1], t);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x8_t*>(sb + s * B_PLANE + plane_off(urow + 64 * u, uk)) = t[s];
+    }
+  };
+  const int frow = lane & 15, fq = lane >> 4;
+  const int lo = frow * 64 + (((fq + 2 * (frow >> 2)) & 3) << 4);
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE + wm * (4 * 1024) + lo;
+    const char* sb = smem + buf * STAGE + NS * A_PLANE + wn * (NI * 1024) + lo;
+    bf16x8_t xs[4][NS], ws[NI][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xs[j][s] = *reinterpret_cast<const bf16x8_t*>(sa + s * A_PLANE + j * 1024);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ws[i][s] = *reinterpret_cast<const bf16x8_t*>(sb + s * B_PLANE + i * 1024);
+    }
+    // cross terms a_s b_t with s + t < NS, smallest first (the order of gemm_nt_k)
+#pragma unroll
+    for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+      for (int sw = 0; sw <= d; ++sw)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[i][sw], xs[j][d - sw], acc[i][j], 0, 0, 0);
+  };
+  load(0);
+  split_write(0);
+  __syncthreads();
+  for (int t = 0; t < kt_total; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < kt_total;
+    if (more) load(t + 1);                                    // global loads in flight under this K-tile's MFMAs
+    compute(buf);
+    if (more) split_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (the fp32 branch of gemm_nt_k)
+  const void* bias = seg ? p.bias1 : p.bias0;
+  const bool splitk = p.ksplit > 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ml = wm * 64 + j * 16 + frow;
+    if (ml >= nrows) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int nl = wn * (NI * 16) + i * 16 + fq * 4;
+      if (nl >= ncols) continue;
+      if (!splitk) { gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]); continue; }
+      float* cp = (float*)p.C + (int64_t)(row0 + ml) * p.ldc + n0 + nl;
+      for (int r = 0; r < 4 && r < ncols - nl; ++r) {
+        float x = acc[i][j][r];
+        if (blockIdx.y == 0) {
+          if (bias) x += ((const float*)bias)[n0 + nl + r];
+          if (p.residual) x += ((const float*)p.residual)[(int64_t)(row0 + ml) * p.ldr + n0 + nl + r];
+        }
+        atomicAdd(cp + r, x);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ event profiling
 struct ProfRec { hipEvent_t a, b; double flops; double bytes; };
 struct ProfState {
@@ -431,6 +572,12 @@ static int& f32_mode() {
   return mode;
 }
 
+// A/B switch (tools): VM_F32_PRESPLIT=0 keeps the in-register split of gemm_nt_k for fp32 operands
+static bool f32_presplit() {
+  static const bool on = [] { const char* e = getenv("VM_F32_PRESPLIT"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bke = 128 / esz, al = 16 / esz;
   if (!a || !a->A || !a->B || !a->C) return VM_ERR_BAD_ARG;
@@ -510,6 +657,16 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
     if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
+  } else if (esz == 4 && a->K2 == 0 && fmode == 2 && bm64 && f32_presplit()) {
+    // operands split once per element while staging (gemm_nt_f32p_k); two products' planes fit the same LDS as the raw fp32 tiles.
+    // (64-row tiles only: the 128-row form with two K-tiles of loads in flight needs 254 VGPRs + 20 spill slots)
+    hipLaunchKernelGGL((gemm_nt_f32p_k<64, 2>), dim3(grid, 1), dim3(256), 2 * 2 * (64 + 128) * 64, (hipStream_t)stream, p);
+  } else if (esz == 4 && a->K2 == 0 && fmode == 3 && bm64 && f32_presplit()) {
+    static std::once_flag once;
+    static bool ok = false;
+    std::call_once(once, [] { ok = hipFuncSetAttribute((const void*)gemm_nt_f32p_k<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (64 + 128) * 64) == hipSuccess; });
+    if (!ok) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return VM_ERR_LAUNCH; }
+    hipLaunchKernelGGL((gemm_nt_f32p_k<64, 3>), dim3(grid, 1), dim3(256), 2 * 3 * (64 + 128) * 64, (hipStream_t)stream, p);
   } else if (esz == 4 && bm64) {
     const int lds = 2 * (64 * 128 + TILE_BYTES);
     switch (fmode) {
