@@ -142,6 +142,10 @@ __device__ __forceinline__ void row_frags(const float* row, bool valid, int h, b
   }
 }
 
+// exp2 of a non-positive argument through v_exp_f32 alone: exp2f() wraps the same instruction in a range fix (v_ldexp, compares, selects)
+// that only matters for results below 2^-126, which may flush to zero here (probabilities)
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 struct AP {
   const float* q; const float* k; const float* v; float* out;
   int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;
@@ -272,20 +276,27 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
         sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
     }
     float mx = NEG_BIG;
+    if (kv0 + 32 > sq.lk) {                       // only the last tile can reach past the keys (wave-uniform branch)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kvpos = kv0 + acc_row(r, h);
-      float x = sa[r] * sc;
-      x = kvpos < sq.lk ? x : NEG_BIG;
-      sa[r] = x;
-      mx = fmaxf(mx, x);
+      for (int r = 0; r < 16; ++r) {
+        const float x = kv0 + acc_row(r, h) < sq.lk ? sa[r] * sc : NEG_BIG;
+        sa[r] = x;
+        mx = fmaxf(mx, x);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = sa[r] * sc;
+        sa[r] = x;
+        mx = fmaxf(mx, x);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = fexp2(m_run - m_new);
     float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float e = exp2f(sa[r] - m_new); sa[r] = e; rs += e; }
+    for (int r = 0; r < 16; ++r) { const float e = fexp2(sa[r] - m_new); sa[r] = e; rs += e; }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
     m_run = m_new;
@@ -430,11 +441,16 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * PITCH + 2 * s + h], dof[s], dp, 0, 0, 0);
       }
     }
+    if (kv0 + 32 > sq.lk || !qvalid) {            // the last key tile, or a query row past the sequence (its lanes' lse2 is not a statistic)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kvpos = kv0 + acc_row(r, h);
-      const float pr = (kvpos < sq.lk && qvalid) ? exp2f(sa[r] * sc - lse2) : 0.f;
-      sa[r] = pr * (dp[r] - dlt) * p.scale;
+      for (int r = 0; r < 16; ++r) {
+        const int kvpos = kv0 + acc_row(r, h);
+        const float pr = (kvpos < sq.lk && qvalid) ? fexp2(sa[r] * sc - lse2) : 0.f;
+        sa[r] = pr * (dp[r] - dlt) * p.scale;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = fexp2(sa[r] * sc - lse2) * (dp[r] - dlt) * p.scale;
     }
     if constexpr (NS > 0) {
 #pragma unroll
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP 
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, h);
       const bool vis = kvalid && (qq0 + qi) < sq.lq;
-      const float pr = vis ? exp2f(sa[r] * sc - sLse[qi]) : 0.f;
+      const float pr = vis ? fexp2(sa[r] * sc - sLse[qi]) : 0.f;
       pa[r] = pr;
       sa[r] = pr * (dp[r] - sDlt[qi]) * p.scale;
     }
