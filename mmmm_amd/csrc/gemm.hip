@@ -492,7 +492,7 @@ extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, do
 
 extern "C" {
 
-int vm_version(void) { return 300; }      /* 300: round 3 (vm_gemm_args.b_nn / f32_split and vm_attn_f32_args.f32_split are part of the structs) */
+int vm_version(void) { return 400; }      /* 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
 
 int vm_device_arch(char* name_host, int len) {
   int dev = 0;
