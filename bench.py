@@ -661,7 +661,7 @@ def main():
             ms_a, fl_a, n_a = K.prof_collect(hip.PROF_ATTN)
             if n_a:
                 stride_a = args.event_stride if not args.all_kernel_events else args.event_stride
-                out['attention'] = {'kernel': 'a32::fwd_k (32-query four-cluster forward) / attn16_dq_k / attn16_dkv_k (vm_attn_*_bf16)', 'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12,
+                out['attention'] = {'kernel': 'a32::fwd_k (32-query four-cluster forward) / attn16_dkv_k + attn16_dq_ds_k (dQ from the stored dS^T) (vm_attn_*_bf16)', 'achieved_tflops': fl_a / (ms_a * 1e-3) / 1e12,
                                     'frac_of_bf16_peak': fl_a / (ms_a * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 'launches': n_a,
                                     'kernel_time_share': ms_a * stride_a * 1e-3 / dt}
             ms_f, fl_f, n_f = K.prof_collect(hip.PROF_GEMM_F32)

@@ -3,10 +3,13 @@
 # each counter set is its own rocprofv3 pass (PMC slots: 8 SQ per pass); prints per-kernel sums divided by the number of dispatches
 R=$PWD; SH=$1; VAR=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
+# the host must not run ahead of a PMC pass (every dispatch is serialised and slow): with thousands of packets queued the profiler's
+# intercept queue overflowed (SIGSEGV inside a launch / "AQL packet is malformed", then a hang) — one launch at a time, and a time limit
+export AMD_SERIALIZE_KERNEL=3
 i=0
 for CS in "$@"; do
   rm -rf /tmp/pmc_ab_$i
-  rocprofv3 --pmc $CS --output-format csv -d /tmp/pmc_ab_$i -o a -- $R/tools/ubench/attn_bench 2 $SH $VAR > /dev/null 2>&1
+  timeout 900 rocprofv3 --pmc $CS --output-format csv -d /tmp/pmc_ab_$i -o a -- $R/tools/ubench/attn_bench 2 $SH $VAR > /dev/null 2>&1
   python3 - /tmp/pmc_ab_$i <<'PY'
 import csv, collections, re, sys, glob
 f = glob.glob(sys.argv[1] + '/**/a_counter_collection.csv', recursive=True)[0]

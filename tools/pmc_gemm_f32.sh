@@ -1,6 +1,9 @@
 R=$PWD; cd /tmp && export TMPDIR=/tmp
+# the host must not run ahead of a PMC pass (every dispatch is serialised and slow): with thousands of packets queued the profiler's
+# intercept queue overflowed (SIGSEGV inside a launch / "AQL packet is malformed", then a hang) — one launch at a time, and a time limit
+export AMD_SERIALIZE_KERNEL=3
 rm -rf $R/gpurun_out/pmc_f32
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f32 -o t -- python3 $R/tools/bench_gemm_f32.py > $R/gpurun_out/pmc_f32.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_f32 -o t -- python3 $R/tools/bench_gemm_f32.py > $R/gpurun_out/pmc_f32.log 2>&1
 cd $R
 python3 - <<PY
 import csv, collections, re

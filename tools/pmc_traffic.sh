@@ -4,9 +4,12 @@
 # full depth, HBM-budget checkpointing), 2 timed steps — PMC collection serialises every dispatch, the planning / calibration steps run
 # the same GEMM shapes. Run on the GPU box; writes gpurun_out/gemm_traffic.json
 R=$PWD; cd /tmp && export TMPDIR=/tmp
+# the host must not run ahead of a PMC pass (every dispatch is serialised and slow): with thousands of packets queued the profiler's
+# intercept queue overflowed (SIGSEGV inside a launch / "AQL packet is malformed", then a hang) — one launch at a time, and a time limit
+export AMD_SERIALIZE_KERNEL=3
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-events --no-peak-probe --also "" > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o t -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-events --no-peak-probe --also "" > $R/gpurun_out/pmc_$c.log 2>&1
 done
 cd $R
 python3 - <<PY
@@ -35,6 +38,10 @@ res = {
                   "bytes_per_launch": (2.0 * out["FETCH_SIZE"][k]["sum"] / out["FETCH_SIZE"][k]["launches"] + out["WRITE_SIZE"][k]["sum"] / out["WRITE_SIZE"][k]["launches"]) * 1024} for k in forms},
  "note": "memory-side (fabric) bytes of the L2s: Infinity Cache hits are counted (MI355X_MICROARCH.md, HBM section), so this is an upper bound of HBM traffic",
 }
-json.dump(res, open("gpurun_out/r2_gemm_traffic.json", "w"), indent=1)
+import sys
+sys.path.insert(0, ".")
+import bench
+res["source_digest"] = bench.gemm_source_digest()          # bench.py only trusts a measurement taken on the sources it runs
+json.dump(res, open("gpurun_out/gemm_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
