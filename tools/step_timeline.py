@@ -44,7 +44,7 @@ P('per-queue kernel time (ms): ' + ', '.join(f'q{q}: {v / 1e6:.1f}' for q, v in 
 
 
 def fam(n):
-    for key, f in (('attn_f32', 'attn f32'), ('gemm256_k', 'gemm bf16'), ('gemm_nt_k<2', 'gemm bf16'), ('gemm_nt_k<4', 'gemm f32'), ('gemm_tn_k', 'gemm bf16'), ('gemm_tn_f32', 'gemm f32'), ('lora_', 'lora'), ('tn_', 'lora'),
+    for key, f in (('attn_f32', 'attn f32'), ('gemm256_k', 'gemm bf16'), ('gemm_nt_k<2', 'gemm bf16'), ('gemm_nt_k<4', 'gemm f32'), ('gemm_nt_f32p_k', 'gemm f32'), ('gemm_tn_k', 'gemm bf16'), ('gemm_tn_f32', 'gemm f32'), ('lora_', 'lora'), ('tn_', 'lora'),
                    ('attn16', 'attn bf16'), ('a32::fwd_k', 'attn bf16'), ('fwd_k<', 'attn bf16'), ('mfma_rate_k', 'ubench'), ('attn_f32', 'attn f32'), ('attn_delta', 'attn bf16'), ('transpose', 'transpose'), ('colsum', 'colsum'), ('norm', 'norm'),
                    ('ew_k', 'elementwise'), ('gelu_tab', 'elementwise'), ('silu', 'elementwise'), ('rope', 'elementwise'), ('gather', 'rows'), ('scatter', 'rows'), ('embedding', 'rows'),
                    ('ce_', 'ce'), ('adamw', 'adamw'), ('dice', 'loss'), ('upsample', 'upsample'), ('lsap', 'loss'), ('im2col', 'patch'), ('vectorized', 'ATen'),
@@ -69,7 +69,7 @@ m_adam = first(lambda n: n.startswith('adamw_k'))
 marks = [('zero_grad, LoRA transposes', t0, m_exp), ('ViT-E + decoder forward', m_exp, m_ce_f), ('heads forward + losses + heads backward', m_ce_f, m_ce_b), ('backward (heads, LM, ViT)', m_ce_b, m_adam),
          ('clip + AdamW', m_adam, t1)]
 # split backward at the last decoder attention backward kernel (attn16_dq_k<128>) = end of the LM backward
-lm_b = [e for s, e, q, n in st if n.startswith(('attn16_dq_k<128', 'attn16_dkv_k<128')) and s >= (m_ce_b or t0)]
+lm_b = [e for s, e, q, n in st if n.startswith(('attn16_dq_k<128', 'attn16_dq_ds_k<128', 'attn16_dkv_k<128')) and s >= (m_ce_b or t0)]
 if lm_b:
     m_lmb = max(lm_b)
     marks[3:4] = [('backward: decoder', m_ce_b, m_lmb), ('backward: ViT-E', m_lmb, m_adam)]
