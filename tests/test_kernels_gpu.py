@@ -664,6 +664,39 @@ def test_attention_backward_workspace_path_equals_recompute_path(dev, K, monkeyp
         assert torch.equal(g_ws, g_re)
 
 
+def test_hand_waited_kernels_are_deterministic_under_load(dev, K):
+    """The kernels whose LDS reads are inline assembly behind hand-placed waits (attention backward with and without the dS^T workspace,
+    the grouped LoRA factor gradients with the dropout pass) must give the same bits on every launch — a missing wait shows up as a
+    launch-to-launch difference long before it shows up against a tolerance. Full-chip shapes, repeated while other work is queued."""
+    torch.manual_seed(0)
+    H, hd, lens = 16, 112, [785] * 8
+    rows = sum(lens)
+    qkv = torch.randn(rows, 3 * H * hd, device=dev).bfloat16()
+    sl = lambda t: (t[:, :H * hd], t[:, H * hd:2 * H * hd], t[:, 2 * H * hd:])
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+    dout = torch.randn(rows, H * hd, device=dev).bfloat16()
+    out, lse = K.attn_fwd(*sl(qkv), cu, 785, H, hd, hd ** -0.5, False)
+    ref = K.attn_bwd(*sl(qkv), out, lse, dout, cu, 785, H, hd, hd ** -0.5, False).clone()
+    M, C_ = 6280, 1792
+    W = torch.randn(M, C_, device=dev).bfloat16()
+    S = torch.randn(M, 64, device=dev).bfloat16()
+    def group():                                                  # (one output slot per item: a slot may appear once per launch)
+        o1 = torch.zeros(6, 64, C_, device=dev); o2 = torch.zeros(6, C_, 64, device=dev)
+        items = []
+        for j in range(6):
+            items += [(W, S, o1[j], True, None, -1, 0.5, 0.05, 1234 + j), (W, S, o2[j], False, None, -1, 0.5, 0.0, 0)]
+        K.tn_skinny_group(items)
+        return o1, o2
+    g1, g2 = group()
+    filler = torch.randn(4096, 4096, device=dev).bfloat16()
+    for i in range(12):
+        K.gemm(filler, filler)                                   # something else in the queue around the launches under test
+        got = K.attn_bwd(*sl(qkv), out, lse, dout, cu, 785, H, hd, hd ** -0.5, False)
+        assert torch.equal(got, ref), f'attention backward differs on launch {i}'
+        h1, h2 = group()
+        assert torch.equal(h1, g1) and torch.equal(h2, g2), f'grouped factor gradients differ on launch {i}'
+
+
 def test_attention_rare_rescale_branch(dev, K):
     # spike one key late in the sequence so the running max jumps in a later tile (guide rule 26)
     H, hd, L = 1, 128, 256
