@@ -457,7 +457,8 @@ def main():
     from mmmm_amd.ddp import grad_production_order
     trainable = grad_production_order(model)       # heads, lm_head, norm, decoder 31..0, embed_tokens, GLU, ViT-E 62..0, patch embedding
     assert len(trainable) == sum(p.requires_grad for p in model.parameters())
-    ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist, order='given')
+    ddp = BucketedGradAllReduce(trainable, world_size=world, force_collectives=use_dist, order='given',
+                                registration=[p for p in model.parameters() if p.requires_grad])
     from mmmm_amd.optim import FlatAdamW
     if args.optimizer == 'flat':       # gradient clip (1.0) + AdamW in one kernel per bucket (mmmm_amd/optim.py)
         opt = FlatAdamW(ddp, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0)

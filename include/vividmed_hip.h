@@ -134,9 +134,19 @@ typedef struct vm_gemm_args {
                                                 weights (35 GB for the 7B decoder + ViT-E) is kept. bf16 output, N % 8 == 0, no split-K. */
   int32_t f32_split;                         /* vm_gemm_f32 only: arithmetic of THIS call. 0 = the process default (vm_gemm_f32_mode),
                                                 1 = exact f32 MFMA, 2 = split-bf16 with 3 products, 3 = split-bf16 with 6 products. */
+  void* workspace; int64_t workspace_bytes;  /* vm_gemm_bf16 / vm_gemm_fp8: device scratch of >= vm_gemm_workspace_bytes() bytes, ZERO-FILLED once when it is
+                                                allocated and owned by ONE stream (launches that may overlap need separate ones), or NULL. With it the library
+                                                may run the shape as a stream-K launch — one persistent workgroup per CU, the tiles that do not fill a whole
+                                                round over the CUs cut along K, fp32 partial tiles handed over through this scratch — when its cost model
+                                                says a partial round would otherwise be paid (e.g. 288 tiles over 256 CUs); results then differ from the
+                                                one-tile-per-workgroup kernel by the fp32 rounding of ONE extra addition per element of a split tile, and are
+                                                bit-identical from launch to launch (the split points and the summation order are functions of the shape and
+                                                of the device-side row counts only). NULL: every tile is computed by one workgroup, as before round 5. */
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);
+/* bytes of vm_gemm_args.workspace that let the library choose the stream-K form on this device (64 MiB + flags on MI355X) */
+int vm_gemm_workspace_bytes(int64_t* bytes_host);
 
 /* LoRA down-projection (peft lora.Linear, conf/lora.yaml r = 64): t[M,64] = drop(x)[M,K] · A[64,K]^T with the
  * inverted dropout of lora_dropout fused on the activation fragment ((seed, row*K+col) hash, same mask as

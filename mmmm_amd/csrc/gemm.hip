@@ -14,6 +14,7 @@
 #include "gemm_common.hpp"
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -492,7 +493,7 @@ extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, do
 
 extern "C" {
 
-int vm_version(void) { return 400; }      /* 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
+int vm_version(void) { return 500; }      /* 500: round 5 (vm_gemm_args.workspace / workspace_bytes, vm_gemm_workspace_bytes); 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
 
 int vm_device_arch(char* name_host, int len) {
   int dev = 0;
@@ -539,31 +540,64 @@ int vm_prof_collect(int kind, double* total_ms_host, double* total_flops_host, i
 }
 
 extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, void* stream);
+extern "C" int vm_gemm256sk_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, int workers, void* workspace,
+                                    unsigned epoch, void* stream);
+extern "C" int64_t vm_gemm256sk_workspace_(int workers);
 
-// Tile choice by estimated rounds over the 256 CUs. Measured on MI355X (tools/bench_gemm_vit.py): one round of 256x256
-// tiles (1 workgroup per CU) costs about 3.0x one round-equivalent of 128x128 tiles (2 co-resident workgroups per CU
-// retire 256 tiles per unit), so 256x256 wins whenever ceil(T256/256) * 3 <= ceil(T128/256). Between the 256-row and the
-// 192-row form of the big tile (same kernel, 16 vs 12 MFMAs per phase: a round of 192-row tiles costs ~0.78 of a round of
-// 256-row ones) the cheaper rounds x cost wins: [6280 x 1792] 1 x 1.0 vs 1 x 0.78, [6280 x 5376] 3 x 1.0 vs 3 x 0.78,
-// [6280 x 15360] 6 x 1.0 vs 8 x 0.78.
-// Returns 0 (128x128 tiles), 256 or 192. VM_GEMM_TILE=128|192|256 forces a choice, -192 only removes the 192-row form
-// from the automatic choice (tests / A-B measurements).
-static int big_tile_rows(int M, int N, int K, bool segmented) {
+// ------------------------------------------------------------------ work scheduler of the 256-column kernel
+// One workgroup per CU: a launch of T tiles costs ceil(T / W) ROUNDS, however little the last one holds. Three ways to run a shape:
+//   DP-256 / DP-192  one tile per workgroup (gemm256_k), 256- or 192-row tiles;
+//   SK-256           stream-K (gemm256sk_k): W persistent workgroups, the T mod W (+ W) leftover tiles cut into W equal K ranges with
+//                    an fp32 slab hand-off, the rest as whole-tile rounds — no partial round, 256-row tiles throughout.
+// Model (us, measured on MI355X with tools/ubench/gemm_bench: DESIGN.md section 3): a K-tile of the 256-row body takes T_K per CU, of the
+// 192-row body 0.78 T_K; every segment a workgroup runs pays a fixed C_SEG (descriptors + first K-tile's latency + output stores); a
+// split tile adds C_FIX (slab out, slab in, flag). The 128-tile kernel (two workgroups per CU) is for shapes with a handful of tiles.
+struct SkPlan { int kind; int rows; };     // kind 0: 128-tile kernel, 1: DP, 2: stream-K
+static int cu_count() {
+  static int n = [] { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+                      return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }();
+  return n;
+}
+// 0 never (default: measured, DESIGN.md section 3 "stream-K": with the operands switched off the stream-K launch of [4128 x 4096] x 4160 takes
+// 112 us against 143 for two rounds of 192-row tiles, with them 203 against 168 — workgroups that share an operand panel no longer walk K in
+// step, every XCD's L2 then fetches each panel once per WORKGROUP instead of once), 1 by the cost model below, 2 whenever legal (tests,
+// tools/ubench/gemm_bench): vm_gemm_sched_mode_
+static int& sk_mode() { static int mode = 0; return mode; }
+extern "C" int vm_gemm_sched_mode_(int mode) { if (mode < 0 || mode > 2) return VM_ERR_BAD_ARG; sk_mode() = mode; return VM_OK; }
+static unsigned sk_next_epoch() { static std::atomic<unsigned> e{0}; unsigned v; do { v = ++e; } while (v == 0); return v; }
+
+// VM_GEMM_TILE=128|192|256 forces the one-tile-per-workgroup kernel with that tile, -192 removes the 192-row form from the choice
+// (tests / A-B measurements). `kt` = K-tiles per output tile (extension included), `tk` = us per K-tile of the 256-row body.
+constexpr double SK_C_SEG = 7.5, SK_C_FIX = 9.0, SK_T_K_BF16 = 1.42, SK_T_K_F8 = 2.0;
+static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool sk_ok) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("VM_GEMM_TILE");
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 128) return 0;
-  if (forced == 256 || forced == 192) return forced;
-  if (K < 128) return 0;
-  const int64_t tn = (N + 255) / 256;
-  const int64_t t256 = (int64_t)((M + 255) / 256 + (segmented ? 1 : 0)) * tn;
-  const int64_t t192 = (int64_t)((M + 191) / 192 + (segmented ? 1 : 0)) * tn;
-  const int64_t t128 = (int64_t)((M + 127) / 128 + (segmented ? 1 : 0)) * ((N + 127) / 128);
-  const int64_t r256 = (t256 + 255) / 256, r192 = (t192 + 255) / 256, r128 = (t128 + 255) / 256;
-  if (r256 * 3 > r128) return 0;
-  return (forced != -192 && r192 * 78 < r256 * 100) ? 192 : 256;
+  if (forced == 128) return {0, 0};
+  if (forced == 256 || forced == 192) return {1, forced};
+  if (kt < 2) return {0, 0};
+  const int W = cu_count();
+  const int64_t tn = (N + 255) / 256, sg = segmented ? 1 : 0;
+  const int64_t t256 = ((M + 255) / 256 + sg) * tn, t192 = ((M + 191) / 192 + sg) * tn;
+  const int64_t t128 = ((M + 127) / 128 + sg) * ((N + 127) / 128);
+  const double work = kt * tk;
+  const double c256 = (double)((t256 + W - 1) / W) * (work + SK_C_SEG);
+  const double c192 = forced == -192 ? 1e30 : (double)((t192 + W - 1) / W) * (0.78 * work + SK_C_SEG);
+  // 128 x 128 tiles, two workgroups per CU: a quarter of a 256-row tile's work at ~0.6 of its rate per workgroup pair
+  const double c128 = (double)((t128 + 2 * W - 1) / (2 * W)) * (0.85 * work + 4.0);
+  double csk = 1e30;
+  if (sk_ok && sk_mode() > 0 && t256 * (int64_t)kt >= 4 * (int64_t)W && (t256 % W)) {
+    const double share = (double)t256 / W;                                      // tiles' worth of K-tiles per worker
+    const int parts = t256 >= W ? 2 : (int)((W + t256 - 1) / t256) + 1;         // workers a split tile is spread over (worst case)
+    csk = share * work + (double)((t256 + W - 1) / W) * SK_C_SEG + SK_C_FIX + 3.0 * (parts - 2);
+    if (sk_mode() == 2) csk = 0.0;
+  }
+  const double cdp = c192 < c256 ? c192 : c256;
+  if (csk < cdp && csk < c128) return {2, 256};
+  if (c128 < cdp) return {0, 0};
+  return {1, c192 < c256 ? 192 : 256};
 }
 
 // fp32 GEMM arithmetic: 0 = exact f32 MFMA, 2 = split-bf16 with 3 products, 3 = split-bf16 with 6 products (default: fp32 products).
@@ -577,6 +611,14 @@ static bool f32_presplit() {
   static const bool on = [] { const char* e = getenv("VM_F32_PRESPLIT"); return !e || atoi(e) != 0; }();
   return on;
 }
+
+// timing-experiment builds (-DVM_GEMM_DEBUG_BUILD): VM_GEMM_DEBUG=<bits> in the environment of the first call, or vm_gemm_debug_set_
+#ifdef VM_GEMM_DEBUG_BUILD
+static int& gemm_dbg() { static int dbg = [] { const char* e = getenv("VM_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); return dbg; }
+extern "C" int vm_gemm_debug_set_(int bits) { gemm_dbg() = bits; return VM_OK; }
+#else
+static int gemm_dbg() { return 0; }
+#endif
 
 static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bke = 128 / esz, al = 16 / esz;
@@ -633,11 +675,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   const int bm = bm64 ? 64 : BM;
   p.tiles_m = (a->M + bm - 1) / bm + (segmented ? 1 : 0);
   p.tiles_n = (a->N + BN - 1) / BN;
-#ifdef VM_GEMM_DEBUG_BUILD
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-#else
-  p.dbg = 0;
-#endif
+  p.dbg = gemm_dbg();
   const int grid = p.tiles_m * p.tiles_n;
   const int kind = esz == 2 ? VM_PROF_GEMM_BF16 : VM_PROF_GEMM_F32;
   if (a->f32_split < 0 || a->f32_split > 3) return VM_ERR_BAD_ARG;
@@ -647,14 +685,19 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (a->b_nn && (esz != 2 || a->out_dtype != VM_BF16 || p.ksplit > 1 || a->N % 8 || (int64_t)a->K * a->ldb * 2 >= (1ll << 31))) return VM_ERR_UNSUPPORTED;
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
-  int big = (esz == 2 && p.ksplit <= 1) ? big_tile_rows(a->M, a->N, a->K + a->K2, segmented) : 0;
+  const bool sk_ok = esz == 2 && !a->b_nn && a->workspace && a->workspace_bytes >= vm_gemm256sk_workspace_(cu_count());
+  SkPlan plan = (esz == 2 && p.ksplit <= 1) ? sched_plan(a->M, a->N, (a->K + a->K2) / 64, SK_T_K_BF16, segmented, sk_ok) : SkPlan{0, 0};
+  int big = plan.kind ? plan.rows : 0;
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
     { static int nt = -1; if (nt < 0) { const char* e = getenv("VM_NN_TILE"); nt = e ? atoi(e) : 192; }
       if (nt == 192 || nt == 256) big = nt; else if (!big) big = 256; }   // default 192: the 256-row NN form spills 15 VGPRs
     p.b_nn = 1;
   }
-  if (big) {
+  if (big && plan.kind == 2 && !a->b_nn) {
+    const int rc = vm_gemm256sk_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 0, cu_count(), a->workspace, sk_next_epoch(), stream);
+    if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
+  } else if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
     if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
   } else if (esz == 4 && a->K2 == 0 && fmode == 2 && bm64 && f32_presplit()) {
@@ -691,6 +734,14 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   return VM_OK;
 }
 
+/* internal (tests, tools): what the scheduler would run for a bf16 shape — kind 0 = 128 x 128 tiles, 1 = one 256-column tile per workgroup, 2 = stream-K */
+int vm_gemm_plan_(int M, int N, int K, int K2, int segmented, int with_workspace, int* kind_host, int* rows_host) {
+  const SkPlan pl = sched_plan(M, N, (K + K2) / 64, SK_T_K_BF16, segmented != 0, with_workspace != 0);
+  if (kind_host) *kind_host = pl.kind;
+  if (rows_host) *rows_host = pl.rows;
+  return VM_OK;
+}
+int vm_gemm_workspace_bytes(int64_t* bytes_host) { if (!bytes_host) return VM_ERR_BAD_ARG; *bytes_host = vm_gemm256sk_workspace_(cu_count()); return VM_OK; }
 int vm_gemm_bf16(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 2); }
 int vm_gemm_f32(const vm_gemm_args* a, void* stream) { return gemm_launch(a, stream, 4); }
 int vm_gemm_f32_mode_get_(void) { return f32_mode(); }      /* internal: the process default as the other translation units see it */
@@ -733,16 +784,14 @@ int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_
   p.ksplit = 1; p.kchunk = a->K;
   p.b_nn = 0;
   p.row_scale = row_scale; p.col_scale0 = col_scale; p.col_scale1 = col_scale_1 ? col_scale_1 : col_scale;
-#ifdef VM_GEMM_DEBUG_BUILD
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-#else
-  p.dbg = 0;
-#endif
-  int big = big_tile_rows(a->M, a->N, a->K / 2 + a->K2, segmented);          /* rounds x cost in bf16-equivalent K-tiles */
-  if (!big) big = 256;                                                        /* the fp8 main loop exists in the 256-column kernel only */
+  p.dbg = gemm_dbg();
+  const bool sk_ok = a->workspace && a->workspace_bytes >= vm_gemm256sk_workspace_(cu_count());
+  SkPlan plan = sched_plan(a->M, a->N, a->K / 128 + a->K2 / 64, SK_T_K_F8, segmented, sk_ok);
+  if (!plan.kind) plan = SkPlan{1, 256};                                      /* the fp8 main loop exists in the 256-column kernel only */
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_GEMM_BF16, stream, &tok);
-  const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 1, stream);
+  const int rc = plan.kind == 2 ? vm_gemm256sk_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, plan.rows, 1, cu_count(), a->workspace, sk_next_epoch(), stream)
+                                : vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, plan.rows, 1, stream);
   if (rc != VM_OK) { vm_prof_end2_(VM_PROF_GEMM_BF16, stream, tok, 0.0, 0.0); return rc; }
   vm_prof_end2_(VM_PROF_GEMM_BF16, stream, tok, 2.0 * (double)a->M * (double)a->N * (double)(a->K + a->K2),
                 ((double)a->M + (double)a->N) * (a->K + 2.0 * a->K2) + (double)a->M * a->N * (a->out_dtype == VM_F32 ? 4 : 2));

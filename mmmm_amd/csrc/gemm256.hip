@@ -157,18 +157,21 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, f32x4_t (&acc)[
 // structure, 12 instead of 16 MFMAs per phase). The 192-row tile exists for tile-count quantisation: [6280 x 1792] is 175
 // tiles of 256 rows (68 % of one round over 256 CUs) but 231 tiles of 192 rows, [6280 x 5376] is 525 (3 rounds) vs 693
 // (3 rounds of 0.75 the work).
-template <bool OUT_F32, int MI, bool F8 = false, bool BNN = false>
-__global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
+//
+// gemm256_segment: output tile (tm, tn) over the MAIN K-tiles [m_begin, m_end) (the LoRA extension tiles belong to the segment
+// that starts at main tile 0). ROLE 0: the whole K range -> epilogue (what the one-tile-per-workgroup kernel runs). The stream-K
+// kernel (gemm256sk_k below) also uses ROLE 1: a K range that does not start at 0 — the fp32 accumulators go to this worker's slab
+// and its flag is published; ROLE 2: a K range [0, m_end) with m_end short of the tile's K — the workers [sk_w0, sk_w1) hold the
+// rest: their slabs are added in worker order (a fixed order: the sum does not depend on who finished when), then the epilogue.
+template <bool OUT_F32, int MI, bool F8, bool BNN, bool SK>
+__device__ __forceinline__ void gemm256_segment(const GemmParams& p, char* smem, const int tid, int tm, int tn, int m_begin, int m_end, int role,
+                                                int sk_self, int sk_w0, int sk_w1) {
   static_assert(!(F8 && BNN), "the NN weight form exists for bf16 only");
   constexpr int BMT = 64 * MI;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  int tm, tn;
-  gemm_tile_id(p, tm, tn);
   int row0, nrows, seg;
   gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
   if (nrows <= 0) return;
@@ -184,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
                                         : make_rsrc(Bw, (int64_t)n0 * ldb_b, VM_DBG(p, 1) ? 0 : ncols * ldb_b);
   // F8: the main operands are e4m3 bytes — a 128-byte LDS row holds 128 k instead of 64, everything else (DMA, swizzle, phases) is
   // unchanged; the LoRA extension tiles stay bf16
-  const int kt_ext = p.K2 / 64, kt_main = F8 ? p.K / 128 : p.K / 64, kt_total = kt_ext + kt_main;
+  // (SK: only the segment that starts at main K-tile 0 carries the extension tiles; a segment always holds >= 1 main tile)
+  const int kt_ext = (!SK || m_begin == 0) ? p.K2 / 64 : 0, kt_main = SK ? m_end - m_begin : (F8 ? p.K / 128 : p.K / 64), kt_total = kt_ext + kt_main;
+  const int m_first = (SK && !VM_DBG(p, 1024)) ? m_begin : 0;      // (timing experiment 1024: every segment reads from k = 0 — aligned K phases, wrong results)
   __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
   int lda2_b = 0, ldb2_b = 0;
   if (kt_ext > 0) {
@@ -197,9 +202,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   auto stage = [&](int t, int h) {
     char* dst = smem + (t & 1) * STAGE_BYTES2 + h * HALF_BYTES;
     const bool ext = t < kt_ext;
-    const int koff = (ext ? t : t - kt_ext) * 128;
+    const int koff = (ext ? t : t - kt_ext + m_first) * 128;
     if (h < 2) stage_half<0, MI>(ext ? rA2 : rA, ext ? lda2_b : lda_b, koff, h, dst, wave, lane);
-    else if (BNN && !ext) stage_half_nn(rB, ldb_b, (t - kt_ext) * 64, h - 2, ncols, dst, wave, lane);
+    else if (BNN && !ext) stage_half_nn(rB, ldb_b, (t - kt_ext + m_first) * 64, h - 2, ncols, dst, wave, lane);
     else stage_half<1>(ext ? rB2 : rB, ext ? ldb2_b : ldb_b, koff, h - 2, dst, wave, lane);
   };
 
@@ -371,6 +376,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #endif
 
+  if constexpr (SK) {
+    // every wave is past its last LDS read and holds no vector-memory operation in flight (the last K-tile waited vmcnt(0))
+    constexpr int SLAB_BYTES = 8 * (8 * MI) * 1024;       // 8 waves x (2 MI x 4) accumulator registers x 64 lanes x 16 B, in register order
+    if (role == 1) {
+      // contributor: accumulators -> slab[sk_self] with write-through (sc1) stores, 1 KiB contiguous per wave-instruction; every wave
+      // drains its stores, the workgroup meets, ONE lane publishes the epoch (guide "Workgroup dispatch ... inter-workgroup visibility":
+      // sc1 payload -> vmcnt(0) of every storing wave -> barrier -> sc1 flag; the consumer polls with sc1 loads and reads with sc1 loads)
+      const __amdgpu_buffer_rsrc_t rS = make_rsrc((const char*)p.sk_slabs, (int64_t)sk_self * SLAB_BYTES, VM_DBG(p, 256) ? 0 : SLAB_BYTES);
+#pragma unroll
+      for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, acc[i][j]), rS, ((wave * (8 * MI) + i * 4 + j) * 64 + lane) * 16, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + sk_self, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if (role == 2 && !VM_DBG(p, 512)) {
+      for (int w = sk_w0; w < sk_w1; ++w) {
+        if (tid == 0) {
+          // bounded spin (the contributor ran its slab FIRST, long before this owner reached the end of its range): give up rather than hang
+          int spins = 0;
+          while (__hip_atomic_load(p.sk_flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) { __hip_atomic_store(p.sk_flags + p.sk_workers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t rS = make_rsrc((const char*)p.sk_slabs, (int64_t)w * SLAB_BYTES, SLAB_BYTES);
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i) {
+          f32x4_t part[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            part[j] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rS, ((wave * (8 * MI) + i * 4 + j) * 64 + lane) * 16, 0, 16));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += part[j];
+        }
+      }
+    }
+  }
+
   if constexpr (F8) {
     // dequantise: acc[m][n] *= row_scale[m] * col_scale[n] (the extension operands were pre-divided by the same scales on the host)
     const float* cs = seg ? p.col_scale1 : p.col_scale0;
@@ -390,6 +438,90 @@ __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
     }
   }
   epilogue256<OUT_F32, MI>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
+}
+
+template <bool OUT_F32, int MI, bool F8 = false, bool BNN = false>
+__global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  gemm_tile_id(p, tm, tn);
+  gemm256_segment<OUT_F32, MI, F8, BNN, false>(p, smem, threadIdx.x, tm, tn, 0, 0, 0, 0, 0, 0);
+}
+
+// Stream-K form: ONE workgroup per CU (grid = p.sk_workers) walks a list of segments.
+//   * real tile count T from the device-side row counts (the token-routed two-segment form launches an upper bound);
+//   * the first Tsk = T mod W (+ W when T >= W) tiles are the stream-K region: their Tsk x km main K-tiles are cut into W equal
+//     contiguous ranges, worker v owns [v U / W, (v + 1) U / W). A range that starts inside a tile begins with a ROLE-1 segment
+//     (slab + flag, done FIRST), a range that ends inside a tile ends with a ROLE-2 segment (done LAST: by then the slabs it needs were
+//     published a whole range ago — the spin is a formality), whole tiles in between are ROLE 0. With U / W >= km (T >= W) a tile has
+//     at most two parts;
+//   * the remaining T - Tsk tiles (a multiple of W) are data-parallel rounds: worker v runs tiles Tsk + v + W j, whole.
+// Worker ids are the XCD-contiguous remap of blockIdx, tiles the GROUP_M-grouped order of gemm_tile_id: workers that share an L2 run
+// neighbouring tiles, in the stream-K region and in the rounds.
+template <bool OUT_F32, int MI, bool F8 = false>
+__global__ __launch_bounds__(512, 2) void gemm256sk_k(const GemmParams p) {
+  constexpr int BMT = 64 * MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int W = gridDim.x;
+  int v = blockIdx.x;
+  { const int q = W >> 3, r = W & 7, xcd = v & 7; v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3); }
+  int M = p.M, split = p.split;
+  if (p.counts_dev) {
+    split = __builtin_amdgcn_readfirstlane(p.counts_dev[0]);
+    M = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
+  }
+  int tiles_m;
+  if (split < 0) tiles_m = (M + BMT - 1) / BMT;
+  else { split = min(split, M); tiles_m = (split + BMT - 1) / BMT + (M - split + BMT - 1) / BMT; }
+  const int tiles_n = p.tiles_n;
+  const int T = tiles_m * tiles_n;
+  const int km = F8 ? p.K / 128 : p.K / 64;
+  int Tsk = (T % W) + ((T >= W && (T % W)) ? W : 0);
+  if ((int64_t)Tsk * km < W) Tsk = 0;      // fewer K-tiles than workers (the device-side row count came out tiny): whole tiles only
+  auto tile_of = [&](int id, int& tm, int& tn) {
+    const int per_group = GROUP_M * tiles_n;
+    const int g = id / per_group, gm0 = g * GROUP_M, gsz = min(GROUP_M, tiles_m - gm0), rem = id - g * per_group;
+    tm = gm0 + rem % gsz;
+    tn = rem / gsz;
+  };
+  auto start_of = [&](int w) { return (int)(((int64_t)w * Tsk * km) / W); };
+  // ONE loop over the worker's segments (one inlined copy of the tile body): the stream-K range first, then the rounds
+  int u = start_of(v);
+  const int u_end = start_of(v + 1);
+  int dp_tile = Tsk + v;
+  while (true) {
+    int tile, m0 = 0, m1 = km, role = 0, w0 = 0, w1 = 0;
+    if (u < u_end) {
+      tile = u / km; m0 = u - tile * km; m1 = min(km, m0 + (u_end - u));
+      if (m0 > 0) role = 1;
+      else if (m1 < km) {
+        // the workers behind this one whose ranges start inside the tile (each non-empty: the launcher requires U >= W)
+        role = 2; w0 = v + 1; w1 = w0;
+        const int tile_end = (tile + 1) * km;
+        while (w1 < W && start_of(w1) < tile_end) ++w1;
+      }
+      u += m1 - m0;
+    } else if (dp_tile < T) {
+      tile = dp_tile; dp_tile += W;
+    } else break;
+    int tm, tn;
+    tile_of(tile, tm, tn);
+    // Nothing the tile body derives from the lane id or from the parameters may be hoisted out of THIS loop: hoisted, the K loop's and the
+    // epilogue's address registers are all live at once (measured: 103 VGPR + 108 SGPR spill slots on a body that sits at 256 VGPRs). The lane
+    // id is laundered and the parameters are re-read from the kernarg segment per segment (scalar loads, ~50 dwords).
+    int tid_l = threadIdx.x;
+    asm volatile("" : "+v"(tid_l));
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
+    kparams_t kp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();      // `p` is the kernel's only argument: offset 0 of the segment
+    asm volatile("" : "+s"(kp));
+    const GemmParams q = *kp;
+#else
+    const GemmParams q = p;
+#endif
+    gemm256_segment<OUT_F32, MI, F8, false, true>(q, smem, tid_l, tm, tn, m0, m1, role, v, w0, w1);
+    __builtin_amdgcn_s_barrier();          // the epilogue's slab reads are done before the next segment stages into the same LDS
+  }
 }
 
 }  // namespace
@@ -428,5 +560,43 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
     else { if (out_f32) VM_G256_LAUNCH(true, 3, false); else VM_G256_LAUNCH(false, 3, false); }
   }
 #undef VM_G256_LAUNCH
+  return VM_OK;
+}
+
+// Stream-K launch (gemm_launch chooses it by cost, gemm.hip: sk_plan): `workers` workgroups, one per CU. The workspace holds
+// `workers` fp32 accumulator slabs, then `workers` + 1 flag words (the last one: the owners' give-up mark, checked by the tests).
+extern "C" int64_t vm_gemm256sk_workspace_(int workers) { return (int64_t)workers * (8 * 32 * 1024) + (int64_t)(workers + 1) * 4; }
+extern "C" int vm_gemm256sk_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, int workers, void* workspace,
+                                    unsigned epoch, void* stream) {
+  GemmParams p = *(const GemmParams*)params;
+  if ((tile_rows != 256 && tile_rows != 192) || workers < 8 || !workspace) return VM_ERR_BAD_ARG;
+  p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);      // upper bound; the kernel counts the real tile rows
+  p.tiles_n = (p.N + 255) / 256;
+  p.sk_slabs = (float*)workspace;
+  p.sk_flags = (unsigned*)((char*)workspace + (int64_t)workers * (8 * 32 * 1024));
+  p.sk_epoch = epoch;
+  p.sk_workers = workers;
+  static std::once_flag attr_once;
+  static bool attr_ok = false;
+  std::call_once(attr_once, [] {
+    const void* fns[8] = {(const void*)gemm256sk_k<false, 4>, (const void*)gemm256sk_k<true, 4>, (const void*)gemm256sk_k<false, 3>,
+                         (const void*)gemm256sk_k<true, 3>, (const void*)gemm256sk_k<false, 4, true>, (const void*)gemm256sk_k<true, 4, true>,
+                         (const void*)gemm256sk_k<false, 3, true>, (const void*)gemm256sk_k<true, 3, true>};
+    bool ok = true;
+    for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) == hipSuccess;
+    attr_ok = ok;
+  });
+  if (!attr_ok) return VM_ERR_LAUNCH;
+  const dim3 grid(workers), block(512);
+  hipStream_t st = (hipStream_t)stream;
+#define VM_SK_LAUNCH(O, M_, F_) hipLaunchKernelGGL((gemm256sk_k<O, M_, F_>), grid, block, LDS_BYTES2, st, p)
+  if (f8) {
+    if (tile_rows == 256) { if (out_f32) VM_SK_LAUNCH(true, 4, true); else VM_SK_LAUNCH(false, 4, true); }
+    else { if (out_f32) VM_SK_LAUNCH(true, 3, true); else VM_SK_LAUNCH(false, 3, true); }
+  } else {
+    if (tile_rows == 256) { if (out_f32) VM_SK_LAUNCH(true, 4, false); else VM_SK_LAUNCH(false, 4, false); }
+    else { if (out_f32) VM_SK_LAUNCH(true, 3, false); else VM_SK_LAUNCH(false, 3, false); }
+  }
+#undef VM_SK_LAUNCH
   return VM_OK;
 }

@@ -37,6 +37,9 @@ struct GemmParams {
   const float* row_scale; const float* col_scale0; const float* col_scale1;
   int b_nn;             // gemm256_k<.., BNN>: the main B operand is stored [contraction][output column] (a weight as it sits in HBM, for dx = dy W)
   int ksplit, kchunk;   // split-K (fp32 atomics into a zeroed C): blockIdx.y owns K range [y*kchunk, (y+1)*kchunk)
+  // stream-K (gemm256sk_k): fp32 accumulator slabs [sk_workers][8 waves][2 MI x 4 registers][64 lanes][4], one flag word per worker
+  // (= sk_epoch once the worker's slab is complete; epochs grow monotonically per process, so nothing is ever re-zeroed)
+  float* sk_slabs; unsigned* sk_flags; unsigned sk_epoch; int sk_workers;
   int dbg;   // timing-experiment builds only (-DVM_GEMM_DEBUG_BUILD): bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
 };
 

@@ -145,12 +145,19 @@ class BucketedGradAllReduce:
 
     def __init__(self, params, process_group=None, bucket_bytes: int = 256 << 20, world_size: int | None = None,
                  force_collectives: bool = False, sync_params: bool = True, order: str = 'reverse', tail_bytes: int | None = None,
-                 defer_average: bool = False):
+                 defer_average: bool = False, registration=None):
         """`order`: 'reverse' = `params` are in registration order, gradients are expected in the reverse of it; 'given' = `params`
         are already in gradient-production order (`grad_production_order(model)`). `defer_average`: finish() leaves the SUM over
-        ranks in the buckets and `grad_scale` = 1/world for the consumer to fold into its own pass (FlatAdamW sets this)."""
+        ranks in the buckets and `grad_scale` = 1/world for the consumer to fold into its own pass (FlatAdamW sets this).
+        `registration` (with order='given'): the same parameters in the order `model.parameters()` yields them — the numbering of
+        optimizer state dicts (`FlatAdamW.state_dict` / `load_state_dict` number by it, so that a checkpoint of `torch.optim.AdamW(
+        model.parameters())`, or of a run with another bucket order, lands on the right parameters: LoRA factors of different layers
+        have identical shapes, a shape check cannot catch a permutation). Defaults to `params` as given."""
         assert order in ('reverse', 'given')
         self.params = [p for p in params if p.requires_grad]
+        self.registration = self.params if registration is None else [p for p in registration if p.requires_grad]
+        if registration is not None and ({id(p) for p in self.registration} != {id(p) for p in self.params} or len(self.registration) != len(self.params)):
+            raise ValueError('`registration` must list exactly the trainable parameters of `params`')
         self._seq = list(reversed(self.params)) if order == 'reverse' else list(self.params)
         self.tail_bytes = tail_bytes
         self.defer_average = defer_average
@@ -186,9 +193,19 @@ class BucketedGradAllReduce:
             p._vm_grad_ready = self._note_stream
             if p.dtype == torch.bfloat16 and p.is_cuda:
                 p._vm_f32_acc = self.f32_accumulator
+        self.register_addresses()
+
+    def register_addresses(self):
+        """(re-)register every parameter under its CURRENT storage address: checkpointed backward nodes see detached aliases of their
+        parameters and find the real ones by address (functional.PARAM_BY_PTR). Whoever re-homes the parameters afterwards
+        (`FlatAdamW` moves them into its flat buffers) must call this again — the old addresses no longer resolve."""
         from . import functional as Fh
-        for p in self.params:          # checkpointed backward nodes see detached aliases of their parameters: find the real ones by address
+        for p in self.params:
+            old = getattr(p, '_vm_reg_ptr', None)
+            if old is not None and old != p.data_ptr() and Fh.PARAM_BY_PTR.get(old) is p:
+                del Fh.PARAM_BY_PTR[old]
             Fh.PARAM_BY_PTR[p.data_ptr()] = p
+            p._vm_reg_ptr = p.data_ptr()
 
     # -- layout ---------------------------------------------------------------------------------
     def _build(self, bucket_bytes: int):

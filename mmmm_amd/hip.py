@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ('ksplit', C.c_int32),
         ('b_nn', C.c_int32),
         ('f32_split', C.c_int32),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
     ]
 
 

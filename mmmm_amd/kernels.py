@@ -39,7 +39,7 @@ def gemm(
     act: int = hip.ACT_NONE,
     counts: torch.Tensor | None = None, split: int = -1,
     drop_p: float = 0.0, drop_seed: int = 0, out_is_zero: bool = False, b_nn: bool = False,
-    f32_split: int = 0, accumulate: bool = False, ksplit_override: int | None = None,
+    f32_split: int = 0, accumulate: bool = False, ksplit_override: int | None = None, workspace: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """out[M,N] = act(a[M,K] @ w[N,K]^T + alpha2 * a2[M,K2] @ b2[N,K2]^T + bias) + residual
 
@@ -48,6 +48,8 @@ def gemm(
     `accumulate` (with an fp32 `out`): out += product — through the split-K atomics when the output is a handful of tiles with a
     long contraction, else through the residual path of the epilogue.
     `f32_split` (fp32 operands): arithmetic of this call — 0 process default, 1 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products.
+    `workspace` (bf16): `gemm_workspace()` — lets the library run the stream-K form where its scheduler asks for it (off by default: measured
+    slower on every shape of the six workloads; `tests/test_gemm_sched_gpu.py` forces it).
     """
     if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
         assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.dtype == torch.bfloat16 and out is None, (a.shape, w.shape)
@@ -119,6 +121,8 @@ def gemm(
     g.ksplit = ksplit
     g.b_nn = 1 if b_nn else 0
     g.f32_split = f32_split if f32 else 0
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = ptr(workspace), workspace.numel()
     hip.call('vm_gemm_f32' if f32 else 'vm_gemm_bf16', C.addressof(g), stream())
     return out
 

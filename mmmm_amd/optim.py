@@ -56,8 +56,9 @@ class CosineLRSchedule:
 
 class FlatAdamW:
     """`lr` may be a float or a callable steps_done -> float (`CosineLRSchedule`). The state dict has torch.optim.AdamW's layout
-    (per-parameter `step` / `exp_avg` / `exp_avg_sq`, two `param_groups`: decayed and undecayed, parameters numbered in the
-    order they were given to the gradient buckets), so a checkpoint written by either loads into the other."""
+    (per-parameter `step` / `exp_avg` / `exp_avg_sq`, two `param_groups`: decayed and undecayed, parameters numbered in REGISTRATION
+    order — `ddp.registration`, i.e. `model.parameters()`, not the production order the buckets are filled in), so a checkpoint written
+    by either loads into the other."""
 
     def __init__(self, ddp: BucketedGradAllReduce, lr=1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  max_grad_norm: float | None = None):
@@ -79,6 +80,7 @@ class FlatAdamW:
                 self.flat_params.append(flat)
                 self.exp_avg.append(torch.zeros_like(flat))
                 self.exp_avg_sq.append(torch.zeros_like(flat))
+        ddp.register_addresses()          # the parameters moved: checkpointed layers resolve their detached aliases by storage address
 
     def current_lr(self) -> float:
         return float(self.lr(self.step_count)) if callable(self.lr) else float(self.lr)
@@ -103,7 +105,8 @@ class FlatAdamW:
         total, coef = self.grad_norm_and_coef() if self.max_grad_norm is not None else (None, None)
         if coef is None and self.ddp.grad_scale != 1.0:
             coef = torch.full((1,), float(self.ddp.grad_scale), dtype=torch.float32, device=self.ddp.buckets[0].buffer.device)
-        self.ddp.grad_scale = 1.0          # consumed: vm_adamw multiplies every gradient by coef as it reads it
+        # (`ddp.grad_scale` stays pending: vm_adamw scales the gradients as it READS them, the buckets still hold the sum over ranks until
+        # `ddp.zero_grad()` — a norm taken after step() must keep applying the factor)
         for b, p, m, v in zip(self.ddp.buckets, self.flat_params, self.exp_avg, self.exp_avg_sq):
             K.adamw_(p, b.buffer, m, v, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay if b.decay else 0.0,
                      step=self.step_count, clip_coef=coef)
@@ -115,14 +118,15 @@ class FlatAdamW:
 
     # -- checkpoint / resume ---------------------------------------------------------------------
     def _slots(self):
-        """(parameter, bucket index, offset) in the order the parameters were handed to the gradient buckets"""
+        """(parameter, bucket index, offset) in REGISTRATION order (`ddp.registration`: what torch.optim numbers by), whatever order the
+        gradient buckets were filled in"""
         where = {}
         for bi, b in enumerate(self.ddp.buckets):
             off = 0
             for p in b.params:
                 where[id(p)] = (bi, off)
                 off += (p.numel() + 7) // 8 * 8
-        return [(p, *where[id(p)]) for p in self.ddp.params]
+        return [(p, *where[id(p)]) for p in self.ddp.registration]
 
     def state_dict(self) -> dict:
         slots = self._slots()

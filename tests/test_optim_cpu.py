@@ -69,6 +69,57 @@ def test_flat_adamw_state_dict_has_torch_layout_and_round_trips():
         opt2.load_state_dict({'state': {}, 'param_groups': [{'params': [0, 1]}]})
 
 
+def test_state_dict_is_numbered_by_registration_order_whatever_the_bucket_order():
+    """buckets filled in gradient-production order (order='given': heads first, layer 0 last) must not renumber the optimizer state: a
+    torch.optim.AdamW(model.parameters()) checkpoint has to land on the same parameters — same-shaped LoRA factors of different layers
+    cannot be told apart by a shape check (advisor, round 4)"""
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.optim import FlatAdamW
+    torch.manual_seed(1)
+    reg = [torch.nn.Parameter(torch.randn(4, 3)) for _ in range(5)]            # five same-shaped parameters, registration order 0..4
+    ropt = torch.optim.AdamW(reg, lr=1e-3, weight_decay=0.01)
+    for i, p in enumerate(reg):
+        p.grad = torch.full_like(p, float(i + 1))
+    ropt.step()
+    sd = ropt.state_dict()
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in reg]
+    production = [mine[i] for i in (4, 2, 3, 0, 1)]                            # what grad_production_order would hand over
+    ddp = BucketedGradAllReduce(production, world_size=1, bucket_bytes=64, order='given', registration=mine)
+    opt = FlatAdamW(ddp, lr=1e-3, weight_decay=0.01)
+    opt.load_state_dict(sd)
+    out = opt.state_dict()
+    for i in range(5):
+        assert torch.equal(out['state'][i]['exp_avg'], sd['state'][i]['exp_avg']), i
+        # and the moments sit in the slot of THAT parameter inside the flat buffers
+        p, bi, off = opt._slots()[i]
+        assert p is mine[i]
+        assert torch.equal(opt.exp_avg[bi][off:off + p.numel()].view_as(p), sd['state'][i]['exp_avg'])
+    with pytest.raises(ValueError):
+        BucketedGradAllReduce(production, world_size=1, order='given', registration=mine[:4])
+
+
+def test_parameters_resolve_by_address_after_the_optimizer_moved_them():
+    """FlatAdamW re-homes every parameter into its flat buffers; the address registry that lets a checkpointed layer find the real
+    Parameter behind a detached alias must follow (advisor, round 4: it kept the old addresses and every alias missed)"""
+    from mmmm_amd import functional as Fh
+    from mmmm_amd.ddp import BucketedGradAllReduce
+    from mmmm_amd.optim import FlatAdamW
+    ps = [torch.nn.Parameter(torch.randn(8, 8)), torch.nn.Parameter(torch.randn(16))]
+    ddp = BucketedGradAllReduce(ps, world_size=1, bucket_bytes=1 << 10)
+    before = [p.data_ptr() for p in ps]
+    assert all(Fh._real_param(p.detach()) is p for p in ps)
+    opt = FlatAdamW(ddp, lr=1e-3)
+    assert all(p.data_ptr() != b for p, b in zip(ps, before))
+    assert all(Fh._real_param(p.detach()) is p for p in ps)
+    assert all(Fh.PARAM_BY_PTR.get(b) is None for b in before)
+    # a deferred 1/world stays pending until the buckets are zeroed (a norm taken after step() still has to apply it)
+    ddp.grad_scale = 0.25
+    assert float(opt.ddp.grad_scale) == 0.25
+    ddp.zero_grad()
+    assert ddp.grad_scale == 1.0
+    ddp.remove()
+
+
 def test_reference_no_weight_decay_set_is_marked():
     """the parameters the reference declares as NoWeightDecayParameter (modeling_cogvlm.py:33, visual.py:32-35,189-190,
     segvol/modeling/image_encoder.py:56) carry the marker here — and nothing else does"""
