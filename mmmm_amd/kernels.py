@@ -28,6 +28,21 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------ GEMM
+_GEMM_WS: dict = {}
+
+
+def gemm_workspace() -> torch.Tensor:
+    """Scratch of the stream-K form of the bf16 / fp8 GEMM (vm_gemm_args.workspace): one zero-filled buffer per (device, stream) — launches
+    on one stream are ordered, launches on different streams may overlap and must not share slabs. 64 MiB each on MI355X."""
+    key = (torch.cuda.current_device(), stream())
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        need = C.c_int64(0)
+        hip.call('vm_gemm_workspace_bytes', C.addressof(need))
+        ws = _GEMM_WS[key] = torch.zeros(need.value, dtype=torch.uint8, device='cuda')
+    return ws
+
+
 def gemm(
     a: torch.Tensor, w: torch.Tensor, *,
     w1: torch.Tensor | None = None,

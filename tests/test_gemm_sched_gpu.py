@@ -61,7 +61,8 @@ def test_stream_k_equals_one_tile_per_workgroup_within_one_ulp_and_replays_bit_f
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     d = (outs[0].float() - ref.float()).abs()
-    ulp = torch.maximum(outs[0].float().abs(), ref.float().abs()) * 2.0 ** -7 + 2.0 ** -7      # one bf16 ulp (+ the residual's cancellation)
+    # one bf16 ulp of the linear's output x = out - residual (rounded BEFORE the residual is added, as torch does) + one of the sum
+    ulp = ((ref.float() - res.float()).abs() + ref.float().abs()) * 2.0 ** -7 + 2.0 ** -9
     assert bool((d <= ulp).all()), float((d / ulp).max())
     assert float((d > 0).float().mean()) < 0.05
     # and both agree with fp32 torch
@@ -103,4 +104,6 @@ def test_scheduler_never_puts_a_chip_filling_shape_on_the_small_tile_kernel(dev)
             for seg in (0, 1):
                 kind, rows = C.c_int(), C.c_int()
                 plan(M, N, Kd, 64, seg, 0, C.addressof(kind), C.addressof(rows))
-                assert kind.value == 1 and rows.value in (192, 256), (M, N, Kd, seg, kind.value)
+                t256 = (-(-M // 256) + seg) * -(-N // 256)
+                if t256 >= 200:          # more than 200 workgroups' worth of 256 x 256 tiles
+                    assert kind.value == 1 and rows.value in (192, 256), (M, N, Kd, seg, kind.value)
