@@ -25,7 +25,9 @@ from pathlib import Path
 import pytest
 import torch
 
-from tests._gpu_common import cpu, oracle_cfg, oracle_state, rel
+import contextlib
+
+from tests._gpu_common import cpu, lora_dropout_on, oracle_cfg, oracle_state, rel
 
 pytestmark = pytest.mark.gpu
 REPORT: dict = {}
@@ -145,52 +147,57 @@ WATCH_HEAD = {False: ('sam.image_encoder.blocks.11.mlp.linear2.weight', 'sam.mas
                      'isam_model.image_encoder.blocks.0.attn.qkv.weight')}
 
 
-@pytest.mark.parametrize('instance', [False, True], ids=['semantic->SAM', 'instance->iSAM'])
-def test_config0_true_width_reduced_depth_end_to_end_vs_oracle(dev, cfg0, instance):
+@pytest.mark.parametrize('instance,drop_p', [(False, 0.0), (True, 0.0), (False, 0.05)],
+                         ids=['semantic->SAM', 'instance->iSAM', 'semantic->SAM, lora_dropout 0.05 (conf/lora.yaml:3)'])
+def test_config0_true_width_reduced_depth_end_to_end_vs_oracle(dev, cfg0, instance, drop_p):
     from oracle import vividmed as O
     from mmmm_amd.data.synthetic import make_batch
     from mmmm_amd.models.mmmm import MyPrecision
     m, tok = cfg0
-    tag = 'iSAM' if instance else 'SAM'
+    tag = ('iSAM' if instance else 'SAM') + (f' p={drop_p}' if drop_p else '')
     batch = make_batch([(3, 1, 224, 224)], [(1, 16, 16)], [(1, 2, 2)], [64], tok=tok, seed=224 + instance, grounding=True, n_pairs=3,
                        instance=[instance], device=dev)
     vi = batch['vlm_inputs']
     assert vi['input_ids'].shape == (1, 117) and int(vi['token_type_ids'].sum()) == 51          # L = 117, Np + 2 = 51 (configs[0])
     batch = MyPrecision().convert_input(batch) | {'host': batch['host']}
     assert batch['image'][0].dtype == torch.bfloat16 and batch['grounding_image'][0].dtype == torch.float32
-    # ---- the step
-    for p in m.parameters():
-        if p.grad is not None:
-            p.grad = None
-    m.logged.clear()
-    loss = m.training_step(batch)
-    loss.backward()
-    # ---- the same forward once more for the intermediate results (LoRA dropout is 0: deterministic)
-    with torch.no_grad():
-        out = m(**vi, image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'], return_dict=True,
-                output_hidden_states=True, materialize_logits=True)
-        prompts = m._get_vg_prompts(vi['input_ids'][:, 1:], out.hidden_states[-1][:, :-1].float(), [None])
-        masks, boxes, disc = m.visual_grounding(vi['input_ids'][:, 1:], out.hidden_states[-1][:, :-1].float(), batch['grounding_image'],
-                                                batch['patch_size'], [None], batch['instance_mask'])
-    assert len(out.hidden_states) == 3 and out.logits.shape == (1, 117, 32008)
-    # ---- the oracle on the host cores: fp32 (exact on the model's weights) and bf16-true
-    scfg = _step_cfg(m, tok)
-    cb = cpu({k: v for k, v in batch.items() if k != 'host'})
-    res = {}
-    for mode in ('fp32', 'bf16'):
-        sd = oracle_state(m)
-        b = dict(cb)
-        if mode == 'bf16':
-            sd = _bf16_true(sd)
-        else:
-            b['image'] = [x.float() for x in b['image']]
-            b['vlm_inputs'] = dict(b['vlm_inputs'], weight=b['vlm_inputs']['weight'].float())
-        watch = WATCH + WATCH_HEAD[instance]
-        sd = {k: (v.requires_grad_(True) if k in watch else v) for k, v in sd.items()}
-        cap: dict = {}
-        l_, log = O.training_step(sd, scfg, b, rope_dtype=torch.bfloat16, capture=cap)
-        l_.backward()
-        res[mode] = dict(loss=l_.detach(), log=log, cap=cap, grads={k: sd[k].grad.float() for k in watch})
+    # (drop_p > 0: every LoRA linear drops, and the oracle is handed the masks the HIP kernels drew — tests/_gpu_common.LoraMasks)
+    with (lora_dropout_on(m, vi, drop_p) if drop_p > 0 else contextlib.nullcontext()) as lmasks:
+        # ---- the step
+        for p in m.parameters():
+            if p.grad is not None:
+                p.grad = None
+        m.logged.clear()
+        loss = m.training_step(batch)
+        loss.backward()
+        # ---- the same forward once more for the intermediate results (the masks are a function of (step, site, element): the same ones)
+        with torch.no_grad():
+            out = m(**vi, image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'], return_dict=True,
+                    output_hidden_states=True, materialize_logits=True)
+            prompts = m._get_vg_prompts(vi['input_ids'][:, 1:], out.hidden_states[-1][:, :-1].float(), [None])
+            masks, boxes, disc = m.visual_grounding(vi['input_ids'][:, 1:], out.hidden_states[-1][:, :-1].float(), batch['grounding_image'],
+                                                    batch['patch_size'], [None], batch['instance_mask'])
+        assert len(out.hidden_states) == 3 and out.logits.shape == (1, 117, 32008)
+        # ---- the oracle on the host cores: fp32 (exact on the model's weights) and bf16-true
+        scfg = _step_cfg(m, tok)
+        cb = cpu({k: v for k, v in batch.items() if k != 'host'})
+        res = {}
+        for mode in ('fp32', 'bf16'):
+            sd = oracle_state(m)
+            b = dict(cb)
+            if mode == 'bf16':
+                sd = _bf16_true(sd)
+            else:
+                b['image'] = [x.float() for x in b['image']]
+                b['vlm_inputs'] = dict(b['vlm_inputs'], weight=b['vlm_inputs']['weight'].float())
+            watch = WATCH + WATCH_HEAD[instance]
+            sd = {k: (v.requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+            cap: dict = {}
+            if lmasks is not None:
+                lmasks.begin()
+            l_, log = O.training_step(sd, scfg, b, rope_dtype=torch.bfloat16, capture=cap)
+            l_.backward()
+            res[mode] = dict(loss=l_.detach(), log=log, cap=cap, grads={k: sd[k].grad.float() for k in watch})
     r32, r16 = res['fp32'], res['bf16']
     am = cb['vlm_inputs']['attention_mask'].bool()
     # ---- loss and logged scalars: exactly the oracle's keys (= the reference's, mmmm.py:333-351)
@@ -236,8 +243,29 @@ def test_config0_true_width_reduced_depth_end_to_end_vs_oracle(dev, cfg0, instan
         # for round 4's, tensor by tensor uncorrelated between the two builds (profiles/r4_parity_seed_sweep.txt, tools/parity_seeds.sh).
         # The language-model-side gradients average over thousands of rows and stay within 0.74 .. 1.38: they keep the 1.5 / 1.8 bound.
         head_side = n.startswith(('vg_proj.', 'sam.', 'isam_model.'))
-        _bounds(f'{tag} grad {n}', ps[n].grad.float().cpu(), r16['grads'][n], r32['grads'][n], a=2.4 if head_side else 1.5,
-                b=2.8 if head_side else 1.8, floor=2e-4)
+        if head_side:
+            # recorded, not bounded (e_hip / e_ref 0.76 .. 2.02 over seeds: a bound wide enough to hold cannot fail) — the deterministic form
+            # of this check follows below
+            REPORT[f'{tag} grad {n} (recorded)'] = dict(e_ref=rel(r16['grads'][n], r32['grads'][n]), e_hip=rel(ps[n].grad.float().cpu(), r32['grads'][n]))
+            continue
+        _bounds(f'{tag} grad {n}', ps[n].grad.float().cpu(), r16['grads'][n], r32['grads'][n], a=1.5, b=1.8, floor=2e-4)
+    # ---- head-side gradients, deterministically: the fp32 islands (vg_proj -> SAM / iSAM -> loss) are fed the ORACLE's bf16 last hidden
+    # state, i.e. bit for bit what the oracle's own islands saw in its bf16-true run; their parameter gradients of the grounding loss
+    # (matching, Dice / focal, box and discriminator terms included) must then agree with that run's to 1e-4 — the language model's
+    # rounding pattern, which made the end-to-end comparison of these tensors a lottery, is the same on both sides.
+    head_names = [n for n in WATCH + WATCH_HEAD[instance] if n.startswith(('vg_proj.', 'sam.', 'isam_model.'))]
+    for n in head_names:
+        ps[n].grad = None
+    h16 = r16['cap']['lm'].hidden_states[-1].detach().to(dev)
+    assert h16.dtype == torch.bfloat16
+    ml, bx, dl = m.visual_grounding(vi['input_ids'][:, 1:], h16[:, :-1].float(), batch['grounding_image'], batch['patch_size'], [None],
+                                    batch['instance_mask'])
+    vg_loss, _ = m._compute_vg_loss(ml, bx, dl, batch['masks'], batch['boxes'], batch['index_offsets'])
+    vg_loss.backward()
+    hg = {n: rel(ps[n].grad.float().cpu(), r16['grads'][n]) for n in head_names}
+    REPORT[f'{tag} head-side gradients on the oracle\'s bf16 hidden state'] = dict(hg, vg_loss=vg_loss.item(), oracle=float(r16['log']['train/vg_loss']))
+    assert abs(vg_loss.item() - float(r16['log']['train/vg_loss'])) <= 1e-4 * max(abs(float(r16['log']['train/vg_loss'])), 1e-3)
+    assert all(v < 1e-4 for v in hg.values()), hg
     # ... and their PARAMETER gradients on identical prompts, true width (the image encoder's blocks run the three-product
     # split-bf16 arithmetic, image_encoder.ENCODER_F32_SPLIT = 2: this is the measurement behind that default)
     head, pre = (m.isam_model, 'isam_model') if instance else (m.sam, 'sam')
@@ -355,4 +383,4 @@ def test_zz_report():
     print('\n' + json.dumps(REPORT, indent=1))
     out = Path(os.environ.get('GRAFT_REPO_ROOT', Path(__file__).resolve().parents[1])) / 'gpurun_out'
     if out.is_dir() and REPORT:
-        (out / os.environ.get('VM_PARITY_REPORT_NAME', 'r4_parity_config0.json')).write_text(json.dumps(REPORT, indent=1))
+        (out / os.environ.get('VM_PARITY_REPORT_NAME', 'r5_parity_config0.json')).write_text(json.dumps(REPORT, indent=1))
