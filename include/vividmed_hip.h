@@ -155,16 +155,6 @@ int vm_gemm_workspace_bytes(int64_t* bytes_host);
 int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
                  int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
                  void* workspace, int64_t workspace_bytes, void* stream);
-/* vm_lora_down whose operand is PRODUCED in the same pass by the element-wise op in front of the LoRA linear: the activation is
- * computed from `x` (and `x2`, same leading dimension) with the standalone kernels' rounding, written once to `y` [M, K] (ldy) and
- * projected — no second pass over the [tokens, intermediate] tensor for the rank-64 product.
- *   mode 1  y = gelu(x)               t = drop(y) A^T     MLP.forward visual.py:126-131: fc2(gelu(fc1(x))), fc2 a peft lora.Linear
- *   mode 2  y = x2 * gelu'(x)         t = y A^T           its backward (x = pre-activation, x2 = dy): A = fc1's lora_B^T, t = u of fc1
- *   mode 3  y = bf16(silu(x)) * x2    t = drop(y) A^T     MLP.forward modeling_cogvlm.py:54-56: down_proj(act(gate) * up), two experts
- * Other arguments as vm_lora_down (A1 / counts_dev / split: the routed two-expert form); workspace from vm_lora_down_workspace. */
-int vm_lora_down_fused(int mode, const void* x, const void* x2, int64_t ldx, void* y, int64_t ldy, const void* A0, const void* A1,
-                       int64_t lda, void* t, int64_t ldt, int M, int K, int R, const int32_t* counts_dev, int split, float drop_p,
-                       uint64_t drop_seed, void* workspace, int64_t workspace_bytes, void* stream);
 /* fp32 scratch the K-split form of vm_lora_down wants for (M, K) (0: none). Without it the kernel runs one pass per
  * 64-row block, which is correct but leaves most CUs idle for M << 16k. The split sum order is fixed (deterministic). */
 int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host);

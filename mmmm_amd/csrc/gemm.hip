@@ -606,11 +606,6 @@ static int& f32_mode() {
   return mode;
 }
 
-// A/B switch (tools): VM_F32_PRESPLIT=0 keeps the in-register split of gemm_nt_k for fp32 operands
-static bool f32_presplit() {
-  static const bool on = [] { const char* e = getenv("VM_F32_PRESPLIT"); return !e || atoi(e) != 0; }();
-  return on;
-}
 
 // timing-experiment builds (-DVM_GEMM_DEBUG_BUILD): VM_GEMM_DEBUG=<bits> in the environment of the first call, or vm_gemm_debug_set_
 #ifdef VM_GEMM_DEBUG_BUILD
@@ -690,8 +685,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   int big = plan.kind ? plan.rows : 0;
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
-    { static int nt = -1; if (nt < 0) { const char* e = getenv("VM_NN_TILE"); nt = e ? atoi(e) : 192; }
-      if (nt == 192 || nt == 256) big = nt; else if (!big) big = 256; }   // default 192: the 256-row NN form spills 15 VGPRs
+    big = 192;                                                            // (the 256-row NN form spills 15 VGPRs)
     p.b_nn = 1;
   }
   if (big && plan.kind == 2 && !a->b_nn) {
@@ -700,11 +694,11 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   } else if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
     if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
-  } else if (esz == 4 && a->K2 == 0 && fmode == 2 && bm64 && f32_presplit()) {
+  } else if (esz == 4 && a->K2 == 0 && fmode == 2 && bm64) {
     // operands split once per element while staging (gemm_nt_f32p_k); two products' planes fit the same LDS as the raw fp32 tiles.
     // (64-row tiles only: the 128-row form with two K-tiles of loads in flight needs 254 VGPRs + 20 spill slots)
     hipLaunchKernelGGL((gemm_nt_f32p_k<64, 2>), dim3(grid, 1), dim3(256), 2 * 2 * (64 + 128) * 64, (hipStream_t)stream, p);
-  } else if (esz == 4 && a->K2 == 0 && fmode == 3 && bm64 && f32_presplit()) {
+  } else if (esz == 4 && a->K2 == 0 && fmode == 3 && bm64) {
     static std::once_flag once;
     static bool ok = false;
     std::call_once(once, [] { ok = hipFuncSetAttribute((const void*)gemm_nt_f32p_k<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (64 + 128) * 64) == hipSuccess; });

@@ -34,20 +34,7 @@ struct DownP {
   const int32_t* counts_dev; int split;
   float drop_p; uint64_t seed;
   float* ws; int ksplits;                   // fp32 partials [ksplits][M][64] when ksplits > 1
-  // fused producer modes (vm_lora_down_fused): x is COMPUTED from `x` / `x2` (same leading dimension) element by element, written to
-  // `y` once, and projected in the same pass
-  const unsigned short* x2; unsigned short* y; int64_t ldy;
 };
-// MODE of lora_down_k: how the projected operand comes about
-//   0  x as stored                                       (vm_lora_down)
-//   1  y = gelu(x)                  [visual.py:129 MLP.forward: fc2(act(fc1(x)))]        t = drop(y) A^T
-//   2  y = x2 * gelu'(x)            [its backward: x = pre-activation, x2 = dy]          t = y B       (u of fc1's LoRA path)
-//   3  y = bf16(silu(x)) * x2       [modeling_cogvlm.py:55 down_proj(act(gate) * up)]    t = drop(y) A^T
-#define VM_LD_PLAIN 0
-#define VM_LD_GELU 1
-#define VM_LD_GELU_BWD 2
-#define VM_LD_SILU_MUL 3
-
 // Streaming skinny GEMM: a workgroup owns 64 rows x one K range. x (the HBM stream) and the 64 x K factor slice are
 // staged per 128-wide K-tile through LDS-DMA (whole 256-byte row segments, 2 stages, 2 workgroups per CU), so the factor
 // is fetched from L2 once per 64 rows instead of once per 16 (the earlier one-slab-per-workgroup form moved 4 bytes of A
@@ -72,10 +59,13 @@ __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t l
 // K-split form, whose grid has more workgroups than CUs. 4: 128 KiB, one workgroup per CU — the single-pass form of a short K
 // ([6280 x 1792]: 99 workgroups of 14 K-tiles; with one tile in flight each of them paid the full memory latency 14 times in a
 // row: 19-23 us for 22.5 MB in situ).
-template <int STAGES, int MODE = VM_LD_PLAIN>
-__global__ __launch_bounds__(256, (STAGES == 2 && MODE < 2) ? 2 : 1) void lora_down_k(const DownP p) {
-  constexpr int NIN = MODE >= 2 ? 2 : 1;                               // element-wise inputs staged per K-tile
-  constexpr int DN_STAGE = (NIN + 1) * DN_BM * ROWB;                   // input tile(s) + factor tile
+// (round 5: the "element-wise producer + projection in one pass" modes of this kernel — GELU, GELU backward, SiLU * up computed on the
+// staged tile, vm_lora_down_fused — are out of the library: bit-identical to the two-kernel form but slower inside the step in all three
+// places, round 3's A B A: 322.5 / 327.6 / 321.9 vs 321.6 ms; DESIGN.md section 3 dead ends)
+template <int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const DownP p) {
+  constexpr int NIN = 1;
+  constexpr int DN_STAGE = (NIN + 1) * DN_BM * ROWB;                   // input tile + factor tile
   extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES * DN_STAGE
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,8 +103,6 @@ __global__ __launch_bounds__(256, (STAGES == 2 && MODE < 2) ? 2 : 1) void lora_d
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
       stage_rows(p.x, p.ldx, row0 + 32 * hlf, live ? max(0, nrows - 32 * hlf) : 0, kt * 128, p.K, sx + hlf * 32 * ROWB, wave, lane);
-      if (NIN == 2)
-        stage_rows(p.x2, p.ldx, row0 + 32 * hlf, live ? max(0, nrows - 32 * hlf) : 0, kt * 128, p.K, sx + (DN_BM + hlf * 32) * ROWB, wave, lane);
       stage_rows(A, p.lda, 32 * hlf, live ? 32 : 0, kt * 128, p.K, sa + hlf * 32 * ROWB, wave, lane);
     }
   };
@@ -129,8 +117,6 @@ __global__ __launch_bounds__(256, (STAGES == 2 && MODE < 2) ? 2 : 1) void lora_d
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) % STAGES;
     // this wave's part of K-tile `kt` has landed (STAGES - 2 tiles stay in flight: 8 DMA instructions per wave and tile) ...
-    // (the element-wise stores of the fused modes are vector-memory operations too: they are younger than the loads waited for)
-    static_assert(STAGES == 2 || MODE == VM_LD_PLAIN, "the counted waits of the deep ring assume loads only");
     if (STAGES == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -141,22 +127,6 @@ __global__ __launch_bounds__(256, (STAGES == 2 && MODE < 2) ? 2 : 1) void lora_d
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       u16x8_t xv = *reinterpret_cast<const u16x8_t*>(sx + tile_off(wave * 16 + frow, 4 * s + fq));
-      if (MODE != VM_LD_PLAIN) {
-        // the operand is produced here, element by element with the standalone kernels' rounding (rowwise.hip ew_k), and written once
-        u16x8_t bv;
-        if (NIN == 2) bv = *reinterpret_cast<const u16x8_t*>(sx + DN_BM * ROWB + tile_off(wave * 16 + frow, 4 * s + fq));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = bf2f(xv[e]);
-          float r;
-          if (MODE == VM_LD_GELU) r = gelu_erf(f);
-          else if (MODE == VM_LD_GELU_BWD) r = gelu_erf_grad(f) * bf2f(bv[e]);
-          else r = bf2f(f2bf(f / (1.0f + __expf(-f)))) * bf2f(bv[e]);
-          xv[e] = f2bf(r);
-        }
-        const int kc = kt * 128 + 32 * s + 8 * fq;
-        if (wave * 16 + frow < nrows && kc + 8 <= p.K) *reinterpret_cast<u16x8_t*>(p.y + m * p.ldy + kc) = xv;
-      }
       if (drop) {
         const int kk = kt * 128 + 32 * s + 8 * fq;
         const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
@@ -862,9 +832,7 @@ extern "C" {
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
-  static const int kt1 = [] { const char* e = getenv("VM_LORA_KT1"); return e ? atoi(e) : 0; }();
-  static const int target = [] { const char* e = getenv("VM_LORA_WANT"); return e ? atoi(e) : 384; }();
-  if (kt <= kt1 && m_tiles >= 64) return 1;
+  constexpr int target = 384;          // ~1.5 workgroups per CU (always split: a single-pass form for short K measured 0.9 ms per step slower)
   int want = (target + m_tiles - 1) / m_tiles;
   want = max(1, min(want, kt / 2));
   const int per = (kt + want - 1) / want;
@@ -878,12 +846,10 @@ int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host) {
   return VM_OK;
 }
 
-static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx, void* y, int64_t ldy, const void* A0, const void* A1,
-                            int64_t lda, void* t, int64_t ldt, int M, int K, int R, const int32_t* counts_dev, int split, float drop_p,
-                            uint64_t drop_seed, void* workspace, int64_t workspace_bytes, void* stream) {
+int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
+                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
+                 void* workspace, int64_t workspace_bytes, void* stream) {
   if (!x || !A0 || !t) return VM_ERR_BAD_ARG;
-  if (mode != VM_LD_PLAIN && (!y || ldy % 8)) return VM_ERR_BAD_ARG;
-  if ((mode == VM_LD_GELU_BWD || mode == VM_LD_SILU_MUL) && !x2) return VM_ERR_BAD_ARG;
   if (M <= 0) return VM_OK;
   if (R != 64 || K % 8 || K < 8 || ldx % 8 || lda % 8 || ldt % 4) return VM_ERR_UNSUPPORTED;
   if ((int64_t)32 * ldx * 2 + 256 >= (1ll << 31) || (int64_t)32 * lda * 2 + 256 >= (1ll << 31)) return VM_ERR_UNSUPPORTED;
@@ -891,7 +857,6 @@ static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx
   if (segmented && !A1) return VM_ERR_BAD_ARG;
   DownP p;
   p.x = (const unsigned short*)x; p.ldx = ldx;
-  p.x2 = (const unsigned short*)x2; p.y = (unsigned short*)y; p.ldy = ldy;
   p.A0 = (const unsigned short*)A0; p.A1 = (const unsigned short*)(A1 ? A1 : A0); p.lda = lda;
   p.t = (unsigned short*)t; p.ldt = ldt;
   p.M = M; p.K = K;
@@ -902,50 +867,22 @@ static int lora_down_launch(int mode, const void* x, const void* x2, int64_t ldx
   p.ws = (float*)workspace;
   if (p.ksplits > 1 && (!workspace || workspace_bytes < (int64_t)p.ksplits * M * 64 * 4)) p.ksplits = 1;   // no workspace: single pass
   const int grid = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
+  const int one = DN_BM * ROWB;
   static bool attr_set = false;
   if (!attr_set) {
-    const int one = DN_BM * ROWB;
-    if (hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_GELU_BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess ||
-        hipFuncSetAttribute((const void*)lora_down_k<2, VM_LD_SILU_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * one) != hipSuccess)
-      return VM_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void*)lora_down_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * one) != hipSuccess) return VM_ERR_LAUNCH;
     attr_set = true;
   }
   // (measured in round 3 and removed: a four-stage ring for single-pass grids — 320.3 vs 320.5 ms per step)
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
-  const dim3 g(grid, p.ksplits), b(256);
-  const int one = DN_BM * ROWB;
-  hipStream_t st = (hipStream_t)stream;
-  switch (mode) {
-    case VM_LD_GELU: hipLaunchKernelGGL((lora_down_k<2, VM_LD_GELU>), g, b, 2 * 2 * one, st, p); break;
-    case VM_LD_GELU_BWD: hipLaunchKernelGGL((lora_down_k<2, VM_LD_GELU_BWD>), g, b, 2 * 3 * one, st, p); break;
-    case VM_LD_SILU_MUL: hipLaunchKernelGGL((lora_down_k<2, VM_LD_SILU_MUL>), g, b, 2 * 3 * one, st, p); break;
-    default:
-      hipLaunchKernelGGL((lora_down_k<2>), g, b, 2 * 2 * one, st, p);
-  }
+  hipLaunchKernelGGL((lora_down_k<2>), dim3(grid, p.ksplits), dim3(256), 2 * 2 * one, (hipStream_t)stream, p);
   if (p.ksplits > 1)
     hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)p.ws, p.t, p.ldt, M, p.ksplits, counts_dev);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * M * 64.0 * K);
   VM_LAUNCH_CHECK();
   return VM_OK;
-}
-
-int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int64_t lda, void* t, int64_t ldt,
-                 int M, int K, int R, const int32_t* counts_dev, int split, float drop_p, uint64_t drop_seed,
-                 void* workspace, int64_t workspace_bytes, void* stream) {
-  return lora_down_launch(VM_LD_PLAIN, x, nullptr, ldx, nullptr, 0, A0, A1, lda, t, ldt, M, K, R, counts_dev, split, drop_p, drop_seed,
-                          workspace, workspace_bytes, stream);
-}
-
-int vm_lora_down_fused(int mode, const void* x, const void* x2, int64_t ldx, void* y, int64_t ldy, const void* A0, const void* A1,
-                       int64_t lda, void* t, int64_t ldt, int M, int K, int R, const int32_t* counts_dev, int split, float drop_p,
-                       uint64_t drop_seed, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (mode != VM_LD_GELU && mode != VM_LD_GELU_BWD && mode != VM_LD_SILU_MUL) return VM_ERR_BAD_ARG;
-  return lora_down_launch(mode, x, x2, ldx, y, ldy, A0, A1, lda, t, ldt, M, K, R, counts_dev, split, drop_p, drop_seed, workspace,
-                          workspace_bytes, stream);
 }
 
 int vm_gemm_tn_bf16(const void* X, int64_t ldx, int P, const void* Y, int64_t ldy, int Q, void* C, int64_t ldc,
@@ -1071,7 +1008,7 @@ int vm_gemm_tn_f32(const float* X, int64_t ldx, int P, const float* Y, int64_t l
   const int tiles = tiles_p * p.tiles_q;
   const int steps = (M + 31) / 32;
   // one workgroup per tile walks all rows when the tiles alone give every CU about a workgroup; otherwise split the rows
-  static const int target = [] { const char* e = getenv("VM_TN_F32_TARGET"); return e ? atoi(e) : 800; }();
+  constexpr int target = 800;
   int splits = 1;
   if (tiles < target / 2) splits = max(1, min(steps / 8, (target + tiles - 1) / tiles));
   p.splits = splits;

@@ -75,8 +75,6 @@ class LinearMeta:
     f8_1: object = None
     # fp32 operands: arithmetic of this layer's three GEMMs (kernels.gemm `f32_split`; 0 = the process default)
     f32_split: int = 0
-    # t = drop(x) A^T computed by the producer of x in the same pass (gelu_lora / silu_mul_lora): the forward skips its own projection
-    t_pre: torch.Tensor | None = None
     # also return x itself (a view): a post-norm block's residual takes THAT output, so the residual's gradient arrives in this
     # node's backward and rides in the dgrad GEMM's epilogue instead of a separate element-wise add over the activations
     fork: bool = False
@@ -356,8 +354,7 @@ class _Linear(Function):
         lora = meta.lora_scale != 0.0 and A0 is not None
         t = None
         if lora:
-            t = meta.t_pre if meta.t_pre is not None else _lora_project(x, A0, A1, meta.gated, counts, meta.drop_p, meta.drop_seed)
-            meta.t_pre = None          # (saved below with the other tensors)
+            t = _lora_project(x, A0, A1, meta.gated, counts, meta.drop_p, meta.drop_seed)
         if meta.f8_0 is not None and meta.act == hip.ACT_NONE:
             # frozen base weight in e4m3 (BASELINE configs[4]): quantise the activation rows, main product on the fp8 MFMA, the LoRA
             # extension in bf16 with its operands pre-divided by the scales the epilogue multiplies back
@@ -407,9 +404,7 @@ class _Linear(Function):
         if lora and (need[1] or need[7] or need[12]):
             Bt0 = meta.Bt0 if meta.Bt0 is not None else _t(B0)
             Bt1 = (meta.Bt1 if meta.Bt1 is not None else _t(B1)) if gated else None
-            u = _take_stashed_u(dy, Bt0)             # computed by the backward of the element-wise op that produced dy, in its own pass
-            if u is None:
-                u = _lora_project(dy, Bt0, Bt1, gated, counts)                            # [M, r] = dy · B
+            u = _lora_project(dy, Bt0, Bt1, gated, counts)                            # [M, r] = dy · B
         if need[1] and meta.f8_0 is not None:
             # fp8 dgrad: dy rows quantised per token, W^T in e4m3 per input channel
             f0, f1 = meta.f8_0, meta.f8_1
@@ -659,108 +654,6 @@ class _Gelu(Function):
 
 def gelu(x):
     return _Gelu.apply(x)
-
-
-# u = dy B of a LoRA linear, computed ahead of time by the backward of the element-wise op whose output gradient dy is
-# (_GeluLora.backward): handed over through a side table keyed by (dy's storage, the B^T it was projected with), taken exactly once.
-_U_STASH: dict = {}
-# Fused "element-wise producer + rank-64 projection" passes (vm_lora_down_fused). Built, bit-identical to the two-kernel form
-# (tests/test_kernels_gpu.py::test_lora_down_fused_producers) and OFF by default: measured inside the step (A B A in one call,
-# 12 timed steps each) GELU forward 322.5 vs 321.6 ms, GELU backward 327.6 vs 321.6 ms, SiLU * up 321.9 vs 321.6 ms. The pass saved
-# (193 MB per ViT layer and direction) is paid back by the structure the projection forces on the element-wise work: 64-row LDS-staged
-# tiles at 1-2 workgroups per CU, where erf on 32 elements per thread and tile (~1.6 us of VALU) no longer overlaps the memory
-# latency — the standalone element-wise kernels run at 4.6-5.4 TB/s with 8 waves per SIMD. Bit 0: GELU forward, bit 1: GELU
-# backward, bit 2: SiLU * up forward.
-FUSE_EW_LORA = int(os.environ.get('VM_FUSE_EW_LORA', '0'))
-
-
-_U_STASH_TASK = [None]
-
-
-def _stash_u(dy: torch.Tensor, Bt: torch.Tensor, u: torch.Tensor):
-    task = torch._C._current_graph_task_id()
-    if task != _U_STASH_TASK[0]:          # keyed on the backward pass, not on "the table is empty": a pass that raised leaves entries behind
-        _U_STASH.clear()
-        _U_STASH_TASK[0] = task
-        torch.autograd.Variable._execution_engine.queue_callback(_U_STASH.clear)
-    _U_STASH[(dy.data_ptr(), Bt.data_ptr())] = (u, dy.shape)
-
-
-def _take_stashed_u(dy: torch.Tensor, Bt0: torch.Tensor):
-    if not _U_STASH:
-        return None
-    hit = _U_STASH.pop((dy.data_ptr(), Bt0.data_ptr()), None)
-    return hit[0] if hit is not None and hit[1] == dy.shape else None
-
-
-class _GeluLora(Function):
-    """a = gelu(h) together with t = drop(a) A^T of the LoRA linear that consumes a (visual.py:126-131: fc2(gelu(fc1(x)))), one pass
-    over [tokens, intermediate] instead of two; the backward computes dh = dy gelu'(h) together with u = dh B of the LoRA linear
-    that PRODUCED h (`Bt_prev` = its lora_B^T, [64, intermediate]) and hands u to that linear's backward (_stash_u)."""
-
-    @staticmethod
-    def forward(ctx, h, A_next, drop_p, seed, Bt_prev):
-        a, t = K.lora_down_fused(K.LD_GELU, h, None, A_next, drop_p=drop_p, drop_seed=seed)
-        ctx.save_for_backward(h, Bt_prev)
-        ctx.mark_non_differentiable(t)
-        return a, t
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, da, _dt):
-        h, Bt = ctx.saved_tensors
-        da = da if da.is_contiguous() else da.contiguous()
-        if Bt is None or not (FUSE_EW_LORA & 2):
-            return K.gelu_bwd(h, da), None, None, None, None
-        dh, u = K.lora_down_fused(K.LD_GELU_BWD, h, da, Bt)
-        _stash_u(dh, Bt, u)
-        return dh, None, None, None, None
-
-
-class _SiluMulLora(Function):
-    """a = bf16(silu(gate)) * up together with t = drop(a) A^T of the (token-type gated) LoRA linear that consumes a
-    (modeling_cogvlm.py:54-56: down_proj(act(gate_proj(x)) * up_proj(x))): one pass over [rows, intermediate] instead of two"""
-
-    @staticmethod
-    def forward(ctx, gate, up, counts, A0, A1, drop_p, seed):
-        a, t = K.lora_down_fused(K.LD_SILU_MUL, gate, up, A0, A1, counts=counts, drop_p=drop_p, drop_seed=seed)
-        ctx.save_for_backward(gate, up)
-        ctx.mark_non_differentiable(t)
-        return a, t
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, da, _dt):
-        gate, up = ctx.saved_tensors
-        dg, du = K.silu_mul_bwd(gate, up, da)
-        return dg, du, None, None, None, None, None
-
-
-def silu_mul_lora(gate, up, counts, A0, A1, drop_p: float, seed: int):
-    """-> (silu(gate) * up, t = drop(.) @ A^T per routed row segment); rows past counts[1] of the first output are not written"""
-    return _SiluMulLora.apply(gate, up, counts, A0.detach(), A1.detach() if A1 is not None else None, drop_p, seed)
-
-
-class _GeluLoraBwdOnly(Function):
-    """standalone GELU forward, fused backward (A/B measurements: VM_FUSE_EW_LORA=2)"""
-    @staticmethod
-    def forward(ctx, h, Bt_prev):
-        ctx.save_for_backward(h, Bt_prev)
-        return K.gelu(h)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, da):
-        return _GeluLora.backward(ctx, da, None)[:2]
-
-
-def gelu_then_lora_bwd(h, Bt_prev):
-    return _GeluLoraBwdOnly.apply(h, Bt_prev)
-
-
-def gelu_lora(h, A_next, drop_p: float, seed: int, Bt_prev=None):
-    """-> (gelu(h), t = drop(gelu(h)) @ A_next^T); A_next [64, K] is read as data (its gradient comes from the consuming linear)"""
-    return _GeluLora.apply(h, A_next.detach(), drop_p, seed, Bt_prev)
 
 
 class _Relu(Function):

@@ -295,33 +295,6 @@ def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None,
     return t
 
 
-LD_GELU, LD_GELU_BWD, LD_SILU_MUL = 1, 2, 3
-
-
-def lora_down_fused(mode: int, x: torch.Tensor, x2: torch.Tensor | None, A0: torch.Tensor, A1: torch.Tensor | None = None, *,
-                    counts: torch.Tensor | None = None, drop_p: float = 0.0, drop_seed: int = 0):
-    """(y, t): the element-wise op in front of a LoRA linear and the linear's rank-64 projection in ONE pass (vm_lora_down_fused):
-    LD_GELU y = gelu(x); LD_GELU_BWD y = x2 * gelu'(x); LD_SILU_MUL y = bf16(silu(x)) * x2; t = drop(y) @ A^T. x, x2 [M, K] bf16
-    contiguous; A [64, K]."""
-    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and A0.shape == (64, x.shape[1])
-    assert x2 is None or (x2.shape == x.shape and x2.dtype == x.dtype and x2.is_contiguous())
-    M, Kd = x.shape
-    y = torch.empty_like(x)
-    t = torch.empty(M, 64, dtype=x.dtype, device=x.device)
-    nbytes = _lora_ws_bytes(M, Kd, counts is not None)
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device) if nbytes else None
-    hip.call('vm_lora_down_fused', mode, ptr(x), ptr(x2), Kd, ptr(y), Kd, ptr(A0), ptr(A1), _ld(A0), ptr(t), _ld(t), M, Kd, 64,
-             ptr(counts), -1, drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF, ptr(ws), nbytes, stream())
-    return y, t
-
-
-@functools.lru_cache(maxsize=256)
-def _lora_ws_bytes(M: int, Kd: int, segmented: bool) -> int:
-    n = C.c_int64(0)
-    hip.call('vm_lora_down_workspace', M, Kd, int(segmented), C.addressof(n))
-    return n.value
-
-
 def lora_down_supported(x: torch.Tensor, A: torch.Tensor) -> bool:
     return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 8 == 0 and x.shape[1] >= 8
 

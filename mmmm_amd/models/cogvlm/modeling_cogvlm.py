@@ -74,11 +74,6 @@ class VisionExpertMLP(nn.Module):
             return linear_decode(h, l.down_proj, residual)
         gate = gated_linear(x, v.gate_proj, l.gate_proj, counts)
         up = gated_linear(x, v.up_proj, l.up_proj, counts)
-        if v.down_proj.fusable_lora(gate, 4) and l.down_proj.lora_cfg is not None and up.is_contiguous():
-            # SwiGLU product and down_proj's rank-64 projection (both experts) in one pass over [rows, 11008]
-            m = v.down_proj.meta()
-            h, t = Fh.silu_mul_lora(gate, up, counts, v.down_proj.A, l.down_proj.A, m.drop_p, m.drop_seed)
-            return gated_linear(h, v.down_proj, l.down_proj, counts, residual=residual, lora_t=t)
         return gated_linear(Fh.silu_mul(gate, up), v.down_proj, l.down_proj, counts, residual=residual)
 
 

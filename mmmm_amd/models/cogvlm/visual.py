@@ -105,16 +105,6 @@ class MLP(nn.Module):
 
     def forward(self, x: torch.Tensor):
         h, x = self.fc1(x, fork=True)
-        fc1, fc2 = self.fc1, self.fc2
-        if h.dim() == 2 and fc2.fusable_lora(h, 3):
-            # GELU and fc2's rank-64 projection t = drop(gelu(h)) A^T in ONE pass over [tokens, 15360]; the backward does the same
-            # for dh = dy gelu'(h) and fc1's u = dh B (functional._GeluLora)
-            m2 = fc2.meta()
-            bt = fc1.lora_t()[1] if (fc1.lora_cfg is not None and torch.is_grad_enabled()) else None
-            if Fh.FUSE_EW_LORA & 1:
-                a, t = Fh.gelu_lora(h, fc2.A, m2.drop_p, m2.drop_seed, bt)
-                return fc2(a, lora_t=t), x
-            return fc2(Fh.gelu_then_lora_bwd(h, bt)), x
         return self.fc2(Fh.gelu(h)), x
 
 

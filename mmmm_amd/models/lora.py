@@ -180,21 +180,14 @@ class Linear(nn.Module):
                 m.drop_seed = StepState.seed_for(self._site)
         return m
 
-    def fusable_lora(self, x: torch.Tensor, bit: int = 1) -> bool:
-        """the producer of `x` may compute this layer's rank-64 projection in its own pass (functional.gelu_lora / silu_mul_lora)"""
-        return (bool(Fh.FUSE_EW_LORA & bit) and self.lora_cfg is not None and self.lora_cfg.r == 64 and self.f8 is None and x.is_cuda
-                and x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and self.in_features % 8 == 0)
-
-    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None, fork: bool = False, lora_t: torch.Tensor | None = None):
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None, fork: bool = False):
         """`fork`: -> (y, x passed through): hand the second output to the block's residual add and the residual's gradient is
-        summed into dx by the dgrad GEMM's epilogue (functional.LinearMeta.fork). `lora_t`: t = drop(x) A^T already computed by the
-        producer of x (with this layer's dropout seed: `meta()`)"""
+        summed into dx by the dgrad GEMM's epilogue (functional.LinearMeta.fork)."""
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         r2 = residual.reshape(-1, self.out_features) if residual is not None else None
         need_dx = torch.is_grad_enabled() and x2.requires_grad
         meta = self.meta()
-        meta.t_pre = lora_t
         meta.fork = fork and Fh.FORK_LINEAR
         y = Fh.linear(x2, self.weight, meta=meta, Wt0=self.wt() if need_dx else None, b0=self.bias, A0=self.A, B0=self.B,
                       residual=r2)
@@ -221,14 +214,11 @@ def linear_decode(x: torch.Tensor, lin: Linear, residual: torch.Tensor | None = 
     return K.gemm(x, lin.weight, a2=t, b2=lin.B, alpha2=scale, bias=lin.bias, residual=residual)
 
 
-def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torch.Tensor, residual: torch.Tensor | None = None,
-                 lora_t: torch.Tensor | None = None):
+def gated_linear(x: torch.Tensor, vision: Linear, language: Linear, counts: torch.Tensor, residual: torch.Tensor | None = None):
     """token-type gated pair of linears on the expert-sorted row layout: rows [0,counts[0]) -> `vision`,
-    rows [counts[0],counts[1]) -> `language` (reference modeling_cogvlm.py:243-245, 277-279, 95-97). `lora_t`: the rank-64 projection
-    of x already computed by its producer (functional.silu_mul_lora, with `vision.meta()`'s dropout seed)."""
+    rows [counts[0],counts[1]) -> `language` (reference modeling_cogvlm.py:243-245, 277-279, 95-97)."""
     need_dx = torch.is_grad_enabled() and x.requires_grad
     m = vision.meta(gated=True)
-    m.t_pre = lora_t
     if language.lora_cfg is not None and vision.lora_cfg is None:
         raise NotImplementedError('LoRA on the language expert only')
     lora_l = language.lora_cfg is not None

@@ -336,11 +336,11 @@ def test_vit_layer_with_the_linear_fork_matches_the_default(dev, K, monkeypatch)
         assert rel_err(p1[n], p0[n]) < 2e-2, n
 
 
-@pytest.mark.parametrize('switch', ['FUSE_EW_LORA', 'NN_DGRAD', 'WGRAD_SIDE_STREAM', 'WGRAD_GROUP_OFF', 'F32_TN_WGRAD_OFF'])
+@pytest.mark.parametrize('switch', ['NN_DGRAD', 'WGRAD_SIDE_STREAM', 'WGRAD_GROUP_OFF', 'F32_TN_WGRAD_OFF'])
 def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch):
     """Alternatives that were measured and left OFF ("dead ends") stay in the library behind module-level switches; each
     is exercised here on a ViT-E-shaped layer with LoRA (dropout on: the mask replay is part of every path) against the default path:
-    FUSE_EW_LORA (element-wise producers fused with the next rank-64 projection), NN_DGRAD (input gradient from the weight as stored),
+    NN_DGRAD (input gradient from the weight as stored),
     WGRAD_SIDE_STREAM (factor gradients on a side stream), and the two old fallbacks WGRAD_GROUP = 0 / F32_TN_WGRAD = 0."""
     from argparse import Namespace
     from mmmm_amd import functional as Fh
@@ -368,9 +368,7 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
     try:
         res = []
         for on in (False, True):
-            if switch == 'FUSE_EW_LORA':
-                monkeypatch.setattr(Fh, 'FUSE_EW_LORA', 7 if on else 0)
-            elif switch == 'WGRAD_GROUP_OFF':
+            if switch == 'WGRAD_GROUP_OFF':
                 monkeypatch.setattr(Fh, 'WGRAD_GROUP', not on)
             elif switch == 'F32_TN_WGRAD_OFF':
                 monkeypatch.setattr(Fh, 'F32_TN_WGRAD', not on)
@@ -798,34 +796,6 @@ def test_tn_skinny_segments(dev, K):
     assert rel_err(a0, 1 + 0.5 * r0.T) < 1e-5 and rel_err(a1, 2 + 0.5 * r1.T) < 1e-5
     empty = torch.tensor([0, 0, 0, 0], dtype=torch.int32, device=dev)
     assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
-
-
-@pytest.mark.parametrize('M,Kd', [(785, 1792), (300, 15360), (64, 136)])
-def test_lora_down_fused_producers(dev, K, M, Kd):
-    """the element-wise op in front of a LoRA linear fused with the linear's rank-64 projection (vm_lora_down_fused): the activation is
-    bit-identical to the standalone element-wise kernel's and the projection to vm_lora_down of that activation (same kernel, same
-    summation order), for GELU, its backward, and SiLU * up with two routed experts"""
-    g = torch.Generator(device=dev).manual_seed(M + Kd)
-    h = torch.randn(M, Kd, device=dev, generator=g).bfloat16()
-    dy = torch.randn(M, Kd, device=dev, generator=g).bfloat16()
-    A = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16()
-    A1 = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16()
-    for p_, seed in ((0.0, 0), (0.1, 77)):
-        y, t = K.lora_down_fused(K.LD_GELU, h, None, A, drop_p=p_, drop_seed=seed)
-        ref = K.gelu(h)
-        assert torch.equal(y, ref) and torch.equal(t, K.lora_down(ref, A, drop_p=p_, drop_seed=seed))
-    y, t = K.lora_down_fused(K.LD_GELU_BWD, h, dy, A)
-    ref = K.gelu_bwd(h, dy)
-    assert torch.equal(y, ref) and torch.equal(t, K.lora_down(ref, A))
-    counts = torch.tensor([M // 3, M - 5, 0, 0], dtype=torch.int32, device=dev)
-    y, t = K.lora_down_fused(K.LD_SILU_MUL, h, dy, A, A1, counts=counts, drop_p=0.05, drop_seed=5)
-    ref = K.silu_mul(h, dy)
-    n = M - 5
-    assert torch.equal(y[:n], ref[:n])
-    assert torch.equal(t[:n], K.lora_down(ref, A, A1, counts=counts, drop_p=0.05, drop_seed=5)[:n])
-    # against plain torch as well (the standalone kernels have their own tests; this guards the wiring)
-    tt = torch.nn.functional.gelu(h.float()).bfloat16().float() @ A.float().T
-    assert rel_err(K.lora_down_fused(K.LD_GELU, h, None, A)[1], tt) < 6e-3
 
 
 @pytest.mark.parametrize('M,P,Q', [(3136, 768, 3072), (3136, 3072, 768), (777, 768, 768), (100, 64, 136), (2049, 2304, 768)])
