@@ -308,6 +308,7 @@ def run_also(workloads: list, args) -> list:
         out.append({'workload': spec, 'description': j['config']['description'], 'dtype': j['dtype'], 'per_gpu_batch': batch, 'value': j['value'],
                     'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'],
                     'mfma_utilisation_step': j['mfma_utilisation_step'], 'model_tflops_per_image': j['model_tflops_per_image'],
+                    'host_enqueue_ms': j.get('host_enqueue_ms'),
                     'gradient_checkpointing': j['config']['gradient_checkpointing'], 'wgrad_side_stream': j['config']['wgrad_side_stream'],
                     'wall_s': round(time.perf_counter() - t0, 1)})
     return out
@@ -414,7 +415,7 @@ def main():
     ap.add_argument('--no-peak-probe', action='store_true', help='skip the 2 s MFMA peak measurement (roofline.peak_measured)')
     ap.add_argument('--also-budget', type=float, default=float(os.environ.get('VM_BENCH_ALSO_BUDGET', '330')),
                     help='seconds of wall clock for the --also children together: a child is only started while the budget lasts (the rest are reported as skipped)')
-    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8'),
+    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8,model-hr-3d'),
                     help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
                          "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
     args = ap.parse_args()

@@ -295,6 +295,13 @@ def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None,
     return t
 
 
+@functools.lru_cache(maxsize=256)
+def _lora_ws_bytes(M: int, Kd: int, segmented: bool) -> int:
+    n = C.c_int64(0)
+    hip.call('vm_lora_down_workspace', M, Kd, int(segmented), C.addressof(n))
+    return n.value
+
+
 def lora_down_supported(x: torch.Tensor, A: torch.Tensor) -> bool:
     return x.dtype == torch.bfloat16 and A.shape[0] == 64 and x.shape[1] % 8 == 0 and x.shape[1] >= 8
 
