@@ -7,6 +7,9 @@
 //  vm_gemm_tn   : C[P,Q] (+)= X[M,P]^T · Y[M,Q]  contracted over token rows (dA, dB, and full weight gradients).
 //                 Both operands are staged row-major exactly as they sit in HBM and fed to the MFMA through
 //                 ds_read_b64_tr_b16 transposed reads, so no transposed copies of activations are ever written.
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
 #include "vm_common.hpp"
 #include "vm_tile.hpp"
 
@@ -34,6 +37,8 @@ struct DownP {
   const int32_t* counts_dev; int split;
   float drop_p; uint64_t seed;
   float* ws; int ksplits;                   // fp32 partials [ksplits][M][64] when ksplits > 1
+  unsigned* tickets;                        // != NULL: one arrival counter per row block (zero between launches) — the workgroup whose add comes
+                                            // last sums the partials itself (no lora_reduce_k launch)
 };
 // Streaming skinny GEMM: a workgroup owns 64 rows x one K range. x (the HBM stream) and the 64 x K factor slice are
 // staged per 128-wide K-tile through LDS-DMA (whole 256-byte row segments, 2 stages, 2 workgroups per CU), so the factor
@@ -144,21 +149,64 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
   (void)DMA_PER_TILE;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-row tail stages
   // D[row = r][col = m_local]: lane holds r = 16 i + 4 fq + 0..3 for row m
-  if (wave * 16 + frow >= nrows) return;
+  const bool row_ok = wave * 16 + frow < nrows;
   if (drop) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] *= inv_keep;
   }
-  if (p.ksplits > 1) {
-    float* w = p.ws + ((int64_t)blockIdx.y * p.M + m) * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(w + 16 * i + 4 * fq) = acc[i];
-  } else {
+  if (p.ksplits <= 1) {
+    if (!row_ok) return;
     unsigned short* o = p.t + m * p.ldt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u16x4_t v = {f2bf(acc[i][0]), f2bf(acc[i][1]), f2bf(acc[i][2]), f2bf(acc[i][3])};
       *reinterpret_cast<u16x4_t*>(o + 16 * i + 4 * fq) = v;
+    }
+    return;
+  }
+  if (!p.tickets) {                      // partials for lora_reduce_k
+    if (!row_ok) return;
+    float* w = p.ws + ((int64_t)blockIdx.y * p.M + m) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(w + 16 * i + 4 * fq) = acc[i];
+    return;
+  }
+  // ---- one launch: partials out with write-through (sc1) stores, every wave drains its stores, the workgroup meets, ONE lane takes a
+  // ticket; the workgroup that drew the last one sums all `ksplits` partials of its row block IN SPLIT ORDER with sc1 loads — the order and
+  // the arithmetic of lora_reduce_k, so the two forms agree bit for bit (guide "Workgroup dispatch ... inter-workgroup visibility": sc1 payload,
+  // vmcnt(0) of every storing wave, barrier, agent-scope counter add; the consumer loads after its add has returned, the other waves after
+  // a barrier it joins; no fence: a release would write back the whole L2 — that form cost 45 -> 117 us in round 1). The counter is back at
+  // zero when the last workgroup leaves.
+  {
+    const int64_t ws_rows = (int64_t)p.ksplits * p.M;                     // rows of 256 bytes
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(p.ws, 0, (int)(ws_rows * 256));
+    const int woff = (int)(((int64_t)blockIdx.y * p.M + m) * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, acc[i]), rW, row_ok ? woff + 64 * i + 16 * fq : 0x7FFFFFF0, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);                            // (every wave is past its last LDS read: the barrier above)
+    if (tid == 0) {
+      unsigned* tk = p.tickets + blockIdx.x;
+      const unsigned got = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = got + 1 == (unsigned)p.ksplits;
+      if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // 64 rows x 16 groups of 4 columns: thread -> 4 (row, group) items, 16 lanes per 256-byte row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int item = tid + 256 * j, r = item >> 4, c = (item & 15) * 4;
+      if (r >= nrows) continue;
+      const int64_t row = row0 + r;
+      f32x4_t a = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(row * 256) + c * 4, 0, 16));
+      for (int sp = 1; sp < p.ksplits; ++sp)
+        a += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(((int64_t)sp * p.M + row) * 256) + c * 4, 0, 16));
+      const u16x4_t v = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+      *reinterpret_cast<u16x4_t*>(p.t + row * p.ldt + c) = v;
     }
   }
 }
@@ -829,6 +877,31 @@ extern "C" {
 // split writes and re-reads M x 64 fp32 partials — but inside the training step, where the side stream's kernels compete for
 // the CUs, 1.5 workgroups per CU is better (step time 376.6 ms vs 378.6 ms at one per CU, 377.4 ms at two). A short K
 // (<= 16 K-tiles) is fastest in a single pass without the reduce launch ([6280 x 1792]: 11.0 us vs 12.8 us).
+// zeroed counter pool of the one-launch K-split form, one per device, allocated on first use — never under stream capture (the decode
+// step's hipGraph: a launch captured before the pool exists keeps the two-kernel form)
+constexpr int LD_TICKET_REGION = 1024, LD_TICKET_REGIONS = 64;
+static unsigned* lora_ticket_pool(hipStream_t stream) {
+  static std::mutex mu;
+  static unsigned* pools[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (pools[dev]) return pools[dev];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  unsigned* ptr = nullptr;
+  const size_t bytes = (size_t)LD_TICKET_REGION * LD_TICKET_REGIONS * sizeof(unsigned);
+  if (hipMalloc(&ptr, bytes) != hipSuccess) return nullptr;
+  if (hipMemset(ptr, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(ptr); return nullptr; }
+  pools[dev] = ptr;
+  return ptr;
+}
+
+static int& lora_two_kernels() { static int v = 0; return v; }
+/* internal (tests, A/B): 0 = by shape (one launch with the last-arriver reduction for <= 2 row blocks, else partials + lora_reduce_k),
+ * 1 = always two kernels (the form before round 5), 2 = one launch whenever legal */
+int vm_lora_down_two_kernels_(int mode) { lora_two_kernels() = (mode >= 0 && mode <= 2) ? mode : 0; return VM_OK; }
+
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
@@ -867,6 +940,18 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   p.ws = (float*)workspace;
   if (p.ksplits > 1 && (!workspace || workspace_bytes < (int64_t)p.ksplits * M * 64 * 4)) p.ksplits = 1;   // no workspace: single pass
   const int grid = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
+  // arrival counters of the one-launch form: a pool of zeroed regions handed out round robin (launches of one stream are ordered and every
+  // launch leaves its region zeroed; two launches would have to be 64 apart AND in flight together to meet in one)
+  // Measured (tools/bench_lora_down_ab.py, bit-identical results): the one-launch form wins where the launch boundary is the cost — the decode
+  // step's M <= 16 rows, 9.9 vs 12.3 us x 160 projections per step — ties at [6280 x 1792] (12.0 vs 12.5) and loses 3 us where one workgroup
+  // ends up summing 6-7 partials ([3648 x 4096]: 15.9 vs 12.5); inside the training step 312.0 vs 310.9 ms (A B A B). So: tiny M only.
+  p.tickets = nullptr;
+  unsigned* pool = lora_ticket_pool((hipStream_t)stream);          // (allocated by the first call outside a stream capture, whatever its shape)
+  const int one_launch_blocks = lora_two_kernels() == 2 ? LD_TICKET_REGION : 2;
+  if (pool && p.ksplits > 1 && lora_two_kernels() != 1 && grid <= one_launch_blocks && (int64_t)p.ksplits * M * 256 < (1ll << 31)) {
+    static std::atomic<unsigned> seq{0};
+    p.tickets = pool + (size_t)(seq++ % LD_TICKET_REGIONS) * LD_TICKET_REGION;
+  }
   const int one = DN_BM * ROWB;
   static bool attr_set = false;
   if (!attr_set) {
@@ -877,7 +962,7 @@ int vm_lora_down(const void* x, int64_t ldx, const void* A0, const void* A1, int
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_LORA, stream, &tok);
   hipLaunchKernelGGL((lora_down_k<2>), dim3(grid, p.ksplits), dim3(256), 2 * 2 * one, (hipStream_t)stream, p);
-  if (p.ksplits > 1)
+  if (p.ksplits > 1 && !p.tickets)
     hipLaunchKernelGGL(lora_reduce_k, dim3((unsigned)(((int64_t)M * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)p.ws, p.t, p.ldt, M, p.ksplits, counts_dev);
   vm_prof_end_(VM_PROF_LORA, stream, tok, 2.0 * M * 64.0 * K);

@@ -798,6 +798,42 @@ def test_tn_skinny_segments(dev, K):
     assert torch.count_nonzero(K.tn_skinny(W, S, transpose_out=True, counts=empty, segment=1, out_dtype=f)) == 0
 
 
+@pytest.mark.parametrize('M,Kd,seg', [(6280, 1792, False), (3648, 4096, True), (300, 15360, False), (5, 4096, False), (1000, 11008, True)])
+def test_lora_down_one_launch_equals_partials_plus_reduce_kernel_bit_for_bit(dev, K, M, Kd, seg):
+    """round 5: the K-split rank-64 projection sums its partials in the launch that produced them (the workgroup whose ticket is the last of
+    its row block, `sc1` stores / loads, no fence) instead of a second `lora_reduce_k` launch — same split order, same additions: every
+    output bit equal to the two-kernel form, launch after launch on changing inputs (a stale partial from the previous launch, or a ticket
+    that did not return to zero, would show up as a different row)"""
+    from mmmm_amd import hip
+    lib = hip.lib()
+    g = torch.Generator(device=dev).manual_seed(M + Kd)
+    A0 = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16()
+    A1 = (torch.randn(64, Kd, device=dev, generator=g) / 8).bfloat16() if seg else None
+    counts = torch.tensor([M // 3, M - 3, 0, 0], dtype=torch.int32, device=dev) if seg else None
+    n = M - 3 if seg else M
+    filler = torch.randn(4096, 4096, device=dev).bfloat16()
+    try:
+        for it in range(12):
+            x = torch.randn(M, Kd, device=dev, generator=g).bfloat16()
+            p_, seed = (0.05, 100 + it) if it % 2 else (0.0, 0)
+            lib.vm_lora_down_two_kernels_(1)
+            ref = K.lora_down(x, A0, A1, counts=counts, drop_p=p_, drop_seed=seed)
+            lib.vm_lora_down_two_kernels_(2)
+            if it % 3 == 0:
+                K.gemm(filler, filler)                     # the projection's workgroups start while another kernel drains
+            out = K.lora_down(x, A0, A1, counts=counts, drop_p=p_, drop_seed=seed)
+            assert torch.equal(out[:n], ref[:n]), (it, (out[:n].float() - ref[:n].float()).abs().max().item())
+        tt = x[:n].float()
+        if p_ > 0:
+            tt = K.dropout(x, p_, seed)[:n].float()
+        full = tt @ A0.float().T
+        if seg:
+            full[M // 3:] = tt[M // 3:] @ A1.float().T
+        assert rel_err(out[:n], full) < 6e-3
+    finally:
+        lib.vm_lora_down_two_kernels_(0)
+
+
 @pytest.mark.parametrize('M,P,Q', [(3136, 768, 3072), (3136, 3072, 768), (777, 768, 768), (100, 64, 136), (2049, 2304, 768)])
 @pytest.mark.parametrize('split', [2, 3])
 def test_gemm_tn_f32(dev, K, M, P, Q, split):
