@@ -552,6 +552,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
       stage_stats(qq0 + 64, buf ^ 1);
       if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, qq0 + 128, wave, lane, pr);
     }
+    // (DS: the counted wait at the end of the tile assumes that NOTHING of this block — the next tile's DMA, the row-index loads — is
+    // issued after the tile's dS^T stores; pinned, not left to the scheduler)
+    if constexpr (DS) __builtin_amdgcn_sched_barrier(0);
     A16_STAMP(0)
     const char* sQ = smem + buf * A16_STAGE;
     const char* sDO = sQ + 64 * ROWB;
@@ -633,7 +636,9 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
     if constexpr (DS) {
       // the tile's four dS^T stores are this wave's youngest memory operations: everything older — the next tile's DMA — has landed at
       // vmcnt(4), and the stores keep flying (vmcnt counts stores on gfx950; __syncthreads() would drain them with its fence)
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      constexpr int DS_STORES_PER_TILE = 2 /* query halves */ * 2 /* 8-byte stores per half */;
+      static_assert(DS_STORES_PER_TILE == 4, "the wait below leaves exactly the tile's dS^T stores in flight: keep it equal to the stores issued above");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DS_STORES_PER_TILE) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {

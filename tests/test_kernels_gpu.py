@@ -686,11 +686,23 @@ def test_hand_waited_kernels_are_deterministic_under_load(dev, K):
         K.tn_skinny_group(items)
         return o1, o2
     g1, g2 = group()
+    # the decoder's form of the same kernels: head width 128, causal, sequence position -> row through `row_of_pos` (expert-sorted rows)
+    H2, hd2, lens2 = 32, 128, [456] * 8
+    rows2 = sum(lens2)
+    qkv2 = torch.randn(rows2, 3 * H2 * hd2, device=dev).bfloat16()
+    sl2 = lambda t: (t[:, :H2 * hd2], t[:, H2 * hd2:2 * H2 * hd2], t[:, 2 * H2 * hd2:])
+    cu2 = torch.tensor([0] + list(torch.tensor(lens2).cumsum(0)), dtype=torch.int32, device=dev)
+    rop = torch.randperm(rows2, device=dev).int()
+    dout2 = torch.randn(rows2, H2 * hd2, device=dev).bfloat16()
+    out2, lse2 = K.attn_fwd(*sl2(qkv2), cu2, 456, H2, hd2, hd2 ** -0.5, True, row_of_pos=rop)
+    ref2 = K.attn_bwd(*sl2(qkv2), out2, lse2, dout2, cu2, 456, H2, hd2, hd2 ** -0.5, True, row_of_pos=rop).clone()
     filler = torch.randn(4096, 4096, device=dev).bfloat16()
     for i in range(12):
         K.gemm(filler, filler)                                   # something else in the queue around the launches under test
         got = K.attn_bwd(*sl(qkv), out, lse, dout, cu, 785, H, hd, hd ** -0.5, False)
         assert torch.equal(got, ref), f'attention backward differs on launch {i}'
+        got2 = K.attn_bwd(*sl2(qkv2), out2, lse2, dout2, cu2, 456, H2, hd2, hd2 ** -0.5, True, row_of_pos=rop)
+        assert torch.equal(got2, ref2), f'causal / row-indirected attention backward differs on launch {i}'
         h1, h2 = group()
         assert torch.equal(h1, g1) and torch.equal(h2, g2), f'grouped factor gradients differ on launch {i}'
 
