@@ -217,18 +217,10 @@ def cpu_baseline(workload: dict, cfg, tok) -> dict:
         loss.backward()
         return time.perf_counter() - t0
 
-    # thread count: all host cores is not the fastest choice for layer-sized GEMMs on a many-core box (round 1 measured 27 s per
-    # layer with 256 threads, vs 4.7 s on the 8 cores of the development container): probe on one 2048 x 4096 x 4096 product
-    a_, b_ = torch.randn(2048, 4096), torch.randn(4096, 4096)
-    best, best_t = 1, None
-    for n in sorted({min(ncpu, k) for k in (8, 16, 32, 64, ncpu)}):
-        torch.set_num_threads(n)
-        a_ @ b_
-        t0 = time.perf_counter()
-        a_ @ b_
-        dt_ = time.perf_counter() - t0
-        if best_t is None or dt_ < best_t:
-            best, best_t = n, dt_
+    # Core-count policy, fixed (round 5): min(32, host threads). All 256 threads of the GPU box are slower than 32 on layer-sized GEMMs (round 1:
+    # 27 s per layer with 256 threads against 4.7 s on 8 cores), and a per-run probe of {8, 16, 32, 64, all} made `cores` — and with it the
+    # value — wander between runs (0.030 / 0.053 / 0.022 images/s in rounds 3 / 4 / 5 on the same method). One number, always measured the same way.
+    best = min(32, ncpu)
     torch.set_num_threads(best)
     t11 = run(1, 1)
     t22 = run(2, 2)
@@ -247,7 +239,7 @@ def cpu_baseline(workload: dict, cfg, tok) -> dict:
     return {'value': 1.0 / per_image, 'unit': 'images/s', 'cores': best, 'kind': 'port',
             'sample': (f'oracle fp32 training_step (forward + backward, LoRA r64, {"SAM-B mask head + losses" if workload["sam"] else "no grounding heads"}) of ONE image '
                        f'of {workload["desc"].split(":")[0]} at the true widths: 1 + 1 layers {t11:.1f} s, 2 + 2 layers {t22:.1f} s, {best} of {ncpu} host threads '
-                       f'(fastest of a probe); depth extrapolated to {nl} + {nv} layers with the decoder layer taking {r:.2f} of the increment (FLOP share)')}
+                       f'(fixed policy: min(32, host threads)); depth extrapolated to {nl} + {nv} layers with the decoder layer taking {r:.2f} of the increment (FLOP share)')}
 
 
 def self_launch(n: int) -> int:
