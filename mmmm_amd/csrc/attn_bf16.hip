@@ -245,6 +245,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
+  const bool wave_on = q0 + wave * 16 < seqlen;        // a wave whose 16 queries all lie past the sequence only stages and meets the barriers
   const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
 
   bf16x8_t qf[KS], dof[KS];
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_k(const AttnP p) {
     const int kv0 = t * 64;
     const bool edge = kv0 + 64 > seqlen || (p.causal && kv0 + 64 > q0 + wave * 16);
     const int lim = p.causal ? min(qpos, seqlen - 1) : seqlen - 1;
-    if constexpr (TRV != 0) {
+    if (!wave_on) {
+    } else if constexpr (TRV != 0) {
       // per 32-key half: S^T / dP^T (16 MFMAs), the half's transposed K fragments issued under the exponentials, dQ (ND MFMAs)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_ds_k(const AttnP p) {
   if (q0 >= seqlen) return;
   const int qpos = q0 + wave * 16 + ln;
   const bool qvalid = qpos < seqlen;
+  const bool wave_on = q0 + wave * 16 < seqlen;
   const int64_t qrow = qvalid ? phys_row(p, seq0 + qpos) : 0;
   f32x4_t dq[ND];
 #pragma unroll
@@ -439,19 +442,21 @@ __global__ __launch_bounds__(NW * 64, 4) void attn16_dq_ds_k(const AttnP p) {
       stage_ds((t + 1) * 64, nb + 64 * ROWB);
       if (t + 2 < nt) a16_rows<NW>(p, seq0, seqlen, (t + 2) * 64, wave, lane, pr);
     }
-    bf16x8_t tk[2][ND], td[2];
+    if (wave_on) {
+      bf16x8_t tk[2][ND], td[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const unsigned ad = trb + buf * A16_STAGE + c * 32 * ROWB;
-      td[c] = tr_asm<64 * ROWB>(ad ^ (wave << 5));
+      for (int c = 0; c < 2; ++c) {
+        const unsigned ad = trb + buf * A16_STAGE + c * 32 * ROWB;
+        td[c] = tr_asm<64 * ROWB>(ad ^ (wave << 5));
 #pragma unroll
-      for (int b = 0; b < ND; ++b) tk[c][b] = tr_asm<0>(ad ^ (b << 5));
+        for (int b = 0; b < ND; ++b) tk[c][b] = tr_asm<0>(ad ^ (b << 5));
+      }
+      tr_wait();
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int b = 0; b < ND; ++b) dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[c][b], td[c], dq[b], 0, 0, 0);
     }
-    tr_wait();
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int b = 0; b < ND; ++b) dq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[c][b], td[c], dq[b], 0, 0, 0);
     A16_WAIT_ALL();
     __syncthreads();
   }
@@ -485,6 +490,10 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
   if (k0 >= seqlen) return;
   const int kpos = k0 + wave * 16 + ln;
   const bool kvalid = kpos < seqlen;
+  // a wave whose 16 keys all lie past the sequence (the last key block of a 785-key sequence holds 17 keys: six of its eight waves)
+  // stages its share of the Q / dO tiles and meets the barriers, nothing else: its MFMAs and exponentials competed with the live
+  // waves of the same SIMDs for nothing
+  const bool wave_on = k0 + wave * 16 < seqlen;
   const int64_t krow = kvalid ? phys_row(p, seq0 + kpos) : 0;
 
   bf16x8_t kf[KS], vf[KS];
@@ -561,6 +570,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
     const float* sL = stats + buf * 128;
     const float* sD = sL + 64;
     const bool edge = qq0 + 64 > seqlen || (p.causal && qq0 < k0 + QB);
+    if (wave_on) {
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
       // S[q][key], dP[q][key] for 32 queries: lane (key = ln, g) holds q = qq0 + 32 hq + 16 jj + 4 g + r
@@ -632,13 +642,15 @@ __global__ __launch_bounds__(NW * 64, 1) void attn16_dkv_k(const AttnP p) {
         }
       }
     }
+    }
     A16_STAMP(1)
     if constexpr (DS) {
       // the tile's four dS^T stores are this wave's youngest memory operations: everything older — the next tile's DMA — has landed at
       // vmcnt(4), and the stores keep flying (vmcnt counts stores on gfx950; __syncthreads() would drain them with its fence)
       constexpr int DS_STORES_PER_TILE = 2 /* query halves */ * 2 /* 8-byte stores per half */;
       static_assert(DS_STORES_PER_TILE == 4, "the wait below leaves exactly the tile's dS^T stores in flight: keep it equal to the stores issued above");
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DS_STORES_PER_TILE) : "memory");
+      if (wave_on) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DS_STORES_PER_TILE) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // (a wave without keys issued no stores)
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {
