@@ -164,7 +164,8 @@ def scale_rows(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
 def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Tensor, *, w1_8: torch.Tensor | None = None,
              sw1: torch.Tensor | None = None, a2: torch.Tensor | None = None, b2: torch.Tensor | None = None, b2_1: torch.Tensor | None = None,
              alpha2: float = 1.0, bias: torch.Tensor | None = None, bias1: torch.Tensor | None = None, residual: torch.Tensor | None = None,
-             out_dtype: torch.dtype = torch.bfloat16, counts: torch.Tensor | None = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
+             out_dtype: torch.dtype = torch.bfloat16, counts: torch.Tensor | None = None, drop_p: float = 0.0, drop_seed: int = 0,
+             workspace: torch.Tensor | None = None) -> torch.Tensor:
     """out[M, N] = sa[m] sw[n] (a8 @ w8^T) + alpha2 (a2 @ b2^T) + bias (+ residual) with e4m3 a8 / w8 (vm_gemm_fp8). a2 / b2 must already
     be divided by sa / sw (functional._Linear does that)."""
     M, Kd = a8.shape
@@ -198,6 +199,8 @@ def gemm_fp8(a8: torch.Tensor, sa: torch.Tensor, w8: torch.Tensor, sw: torch.Ten
     g.out_dtype = dtype_code(out.dtype)
     g.drop_p, g.drop_seed = drop_p, drop_seed & 0xFFFFFFFFFFFFFFFF
     g.alpha, g.ksplit = 1.0, 0
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = ptr(workspace), workspace.numel()
     hip.call('vm_gemm_fp8', C.addressof(g), ptr(sa), ptr(sw), ptr(sw1), stream())
     return out
 

@@ -94,6 +94,27 @@ def test_stream_k_fp32_output_and_device_side_row_count(dev, K, streamk):
     torch.testing.assert_close(out[:2500], full[:2500], rtol=2e-3, atol=2e-3)
 
 
+def test_stream_k_fp8_main_product_with_bf16_extension(dev, K, streamk):
+    """the e4m3 form of the same kernel (vm_gemm_fp8): the row / column scales are applied AFTER the partial tiles are summed"""
+    M, N, Kd = 1300, 1792, 2048
+    g = torch.Generator(device='cpu').manual_seed(9)
+    a = torch.randn(M, Kd, generator=g).to(dev).bfloat16()
+    w = (torch.randn(N, Kd, generator=g) / math.sqrt(Kd)).to(dev).bfloat16()
+    a8, sa, inv_sa = K.quant_rows_fp8(a)
+    w8, sw, inv_sw = K.quant_rows_fp8(w)
+    a2 = torch.randn(M, 64, generator=g).to(dev).bfloat16()
+    b2 = (torch.randn(N, 64, generator=g) * 0.05).to(dev).bfloat16()
+    a2s, b2s = K.scale_rows(a2, inv_sa), K.scale_rows(b2, inv_sw)
+    bias = torch.randn(N, generator=g).to(dev).bfloat16()
+    ref = K.gemm_fp8(a8, sa, w8, sw, a2=a2s, b2=b2s, bias=bias)
+    outs = [K.gemm_fp8(a8, sa, w8, sw, a2=a2s, b2=b2s, bias=bias, workspace=K.gemm_workspace()) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    d = (outs[0].float() - ref.float()).abs()
+    assert bool((d <= ref.float().abs() * 2.0 ** -7 + 2.0 ** -9).all()) and float((d > 0).float().mean()) < 0.05
+    full = (a8.view(torch.float8_e4m3fn).float() * sa[:, None]) @ (w8.view(torch.float8_e4m3fn).float() * sw[:, None]).T + a2.float() @ b2.float().T + bias.float()
+    assert ((outs[0].float() - full).norm() / full.norm()).item() < 1e-2
+
+
 def test_scheduler_never_puts_a_chip_filling_shape_on_the_small_tile_kernel(dev):
     """round 4's chooser sent the decoder's N = 4096 linears at 4128 / 4176 rows (288 tiles of 256 rows = 1.06 rounds) to the 128 x 128 kernel"""
     from mmmm_amd import hip
