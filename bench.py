@@ -380,7 +380,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--hbm-fraction', type=float, default=0.70,
+    ap.add_argument('--hbm-fraction', type=float, default=0.76,
                     help='--checkpointing hbm: reserved-memory target of the calibration steps (the pool settles ~10 %% of the HBM above it)')
     ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
