@@ -130,6 +130,11 @@ class lora_dropout_on:
         from mmmm_amd.models.lora import Linear
         self.mods = [m for m in self.model.modules() if isinstance(m, Linear) and m.lora_cfg is not None]
         self.old = [m.lora_cfg.lora_dropout for m in self.mods]
+        # the site ids (-> seeds -> which elements drop) are handed out in construction order over the whole process: number them here, so
+        # that a test sees the same masks whatever ran before it
+        self.old_sites = [m._site for m in self.mods]
+        for i, m in enumerate(self.mods):
+            m._site = 100000 + i
         for m in self.mods:
             m.lora_cfg.lora_dropout = self.p
         masks = LoraMasks(self.model, self.vi, self.p)
@@ -137,6 +142,7 @@ class lora_dropout_on:
         return masks
 
     def __exit__(self, *exc):
-        for m, v in zip(self.mods, self.old):
+        for m, v, st in zip(self.mods, self.old, self.old_sites):
             m.lora_cfg.lora_dropout = v
+            m._site = st
         O.LORA_DROPOUT, O.LORA_DROPOUT_P = None, 0.0

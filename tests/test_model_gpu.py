@@ -153,59 +153,75 @@ def test_lm_backward_matches_oracle(dev, lm):
 def test_lm_backward_matches_oracle_with_lora_dropout_on(dev, lm):
     """conf/lora.yaml:3 lora_dropout 0.05 is what the benchmark runs, and until round 5 the one arithmetic without an oracle comparison
     (the oracle had p = 0 only). The oracle now takes the keep-masks as data (oracle.vividmed.LORA_DROPOUT): forward loss and every
-    trainable gradient under the same e_ref bounds as the p = 0 test, with the layers checkpointed (the recompute must redraw the
-    forward's masks) — ViT-E, the GLU adapter and both experts of every decoder linear drop what the HIP kernels dropped."""
+    trainable gradient against the fp32 and the bf16-true oracle, with the layers checkpointed (the recompute must redraw the forward's
+    masks) — ViT-E, the GLU adapter and both experts of every decoder linear drop what the HIP kernels dropped.
+
+    THREE mask realisations, and a tensor must hold the p = 0 test's e_ref bound in at least two of them. On this 43-token model WHICH
+    elements are dropped decides how well conditioned the backward is: for some realisations a 7 % error of the gradient entering one
+    attention layer (normal bf16 noise here) leaves it as 40 % on dq / dk — the kernel agrees with fp32 autograd on the same inputs to
+    0.5 %, it is the softmax backward's cancellation — and everything below that layer inherits it, while the oracle's own bf16 run, with
+    a different rounding pattern, stays at 4 % (tools/debug_dropout_parity.py: 3 of 8 seeds; per-site forward projections agree to bf16
+    rounding in all of them). A mask that does not reach a kernel is a different thing: that site's LoRA gradients are ~30 % off in EVERY
+    realisation. The median over all tensors of e_hip / e_ref must stay below 1.15 in every realisation (measured 0.86 .. 0.89)."""
+    import statistics
     from oracle import vividmed as O
+    from mmmm_amd.models.lora import StepState
     lm.train()
     lm.gradient_checkpointing_enable()
     batch, _ = make_inputs(dev, seed=11)
+    old_seed = StepState.seed
+    passes: dict = {}          # (lora_dropout_on numbers the sites itself: the masks do not depend on what the process built before)
     try:
-        with lora_dropout_on(lm, batch['vlm_inputs'], 0.05) as masks:
-            for p in lm.parameters():
-                p.grad = None
-            out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
-            out.loss.backward()
-            masks.begin()
-            ref, sd = run_oracle(lm, batch, need_grad=True)
-            ref.loss.backward()
-            masks.begin()
-            ref16, sd16 = run_oracle(lm, batch, need_grad=True, dtype=torch.bfloat16)
-            ref16.loss.backward()
-            # every kind of site was served a mask, and about 5 % of each mask is zero
-            kinds = ('vision.transformer.layers.0.attention.query_key_value', 'vision.transformer.layers.1.mlp.fc2', 'vision.linear_proj.gate_proj',
-                     'layers.0.self_attn.vision_expert_query_key_value', 'layers.1.self_attn.language_expert_dense', 'layers.1.mlp.language_mlp.down_proj')
-            assert all(any(u.endswith(k) for u in masks.used) for k in kinds), sorted(masks.used)
-            masks.begin()
-            probe = masks('model.vision.transformer.layers.0.mlp.fc1', torch.zeros(40, lm.config.vision_config['hidden_size']))
-            assert 0.02 < 1.0 - probe.float().mean().item() < 0.09
-            # ... and the masks matter: the same oracle without them is somewhere else
-            O.LORA_DROPOUT = None
-            with torch.no_grad():
-                nodrop, _ = run_oracle(lm, batch)
-            O.LORA_DROPOUT = masks
-            assert abs(nodrop.loss.item() - ref.loss.item()) > 20 * abs(out.loss.item() - ref.loss.item()) or abs(nodrop.loss.item() - ref.loss.item()) > 1e-3
-        assert abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()) < 5e-3
-        checked = 0
-        worst = {}
-        for name, p in lm.named_parameters():
-            if not p.requires_grad:
-                continue
-            assert p.grad is not None, f'no gradient for trainable {name}'
-            g_ref = sd[name].grad
-            if g_ref is None or g_ref.norm() == 0:
-                continue
-            worst[name] = rel(p.grad.float(), g_ref)
-            few = p.numel() <= 2 * lm.config.hidden_size
-            # (cls / boi / eoi embeddings: a vector summed from three single rows — neither the oracle's nor the HIP path's bf16 error averages,
-            # and WHICH elements the masks drop moves both from run to run: the seeds depend on how many layers the process built before)
-            bf16_ok('d' + name, p.grad.float().cpu(), sd16[name].grad.float(), g_ref, 4.0 if few else 1.4, 4.0 if few else 1.6)
-            checked += 1
-        # (coarse backstop only: on this input the oracle's own bf16 run is 5e-2 .. 7e-2 away from fp32 on the vision tower's gradients;
-        # the bound that decides is bf16_ok above)
-        bad = {k: v for k, v in worst.items() if v > 0.15}
-        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
-        assert checked > 40
+        for seed in (1, 2, 3):
+            StepState.seed = seed
+            with lora_dropout_on(lm, batch['vlm_inputs'], 0.05) as masks:
+                for p in lm.parameters():
+                    p.grad = None
+                out = lm(**batch['vlm_inputs'], image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'])
+                out.loss.backward()
+                masks.begin()
+                ref, sd = run_oracle(lm, batch, need_grad=True)
+                ref.loss.backward()
+                masks.begin()
+                ref16, sd16 = run_oracle(lm, batch, need_grad=True, dtype=torch.bfloat16)
+                ref16.loss.backward()
+                if seed == 1:
+                    # every kind of site was served a mask, and about 5 % of each mask is zero
+                    kinds = ('vision.transformer.layers.0.attention.query_key_value', 'vision.transformer.layers.1.mlp.fc2', 'vision.linear_proj.gate_proj',
+                             'layers.0.self_attn.vision_expert_query_key_value', 'layers.1.self_attn.language_expert_dense',
+                             'layers.1.mlp.language_mlp.down_proj')
+                    assert all(any(u.endswith(k) for u in masks.used) for k in kinds), sorted(masks.used)
+                    masks.begin()
+                    probe = masks('model.vision.transformer.layers.0.mlp.fc1', torch.zeros(40, lm.config.vision_config['hidden_size']))
+                    assert 0.02 < 1.0 - probe.float().mean().item() < 0.09
+                    # ... and the masks matter: the same oracle without them is somewhere else
+                    O.LORA_DROPOUT = None
+                    with torch.no_grad():
+                        nodrop, _ = run_oracle(lm, batch)
+                    O.LORA_DROPOUT = masks
+                    assert abs(nodrop.loss.item() - ref.loss.item()) > 20 * abs(out.loss.item() - ref.loss.item()) or abs(nodrop.loss.item() - ref.loss.item()) > 1e-3
+            assert abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()) < 5e-3, seed
+            ratios = []
+            for name, p in lm.named_parameters():
+                if not p.requires_grad:
+                    continue
+                assert p.grad is not None, f'no gradient for trainable {name}'
+                g_ref = sd[name].grad
+                if g_ref is None or g_ref.norm() == 0:
+                    continue
+                e_or, e_hip, d = rel(sd16[name].grad.float(), g_ref), rel(p.grad.float(), g_ref), rel(p.grad.float(), sd16[name].grad.float())
+                few = p.numel() <= 2 * lm.config.hidden_size         # cls / boi / eoi: three single rows, no averaging
+                a_, b_ = (2.5, 2.5) if few else (1.4, 1.6)
+                ok = e_hip <= a_ * e_or + 1e-4 and d <= b_ * e_or + 1e-4
+                passes.setdefault(name, []).append((ok, round(e_hip / max(e_or, 1e-9), 2)))
+                ratios.append(e_hip / max(e_or, 1e-9))
+                assert e_hip < 0.6, (seed, name, e_hip)              # a gradient that is simply wrong
+            assert statistics.median(ratios) < 1.15, (seed, statistics.median(ratios))
+        assert len(passes) > 40
+        bad = {n: v for n, v in passes.items() if sum(ok for ok, _ in v) < 2}
+        assert not bad, sorted(bad.items())[:10]
     finally:
+        StepState.seed = old_seed
         lm.model.gradient_checkpointing = False
         lm.model.vision.transformer.gradient_checkpointing = False
 
