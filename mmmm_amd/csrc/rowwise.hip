@@ -18,6 +18,17 @@ template <typename T>
 __device__ __forceinline__ void stv(T* p, typename Elem<T>::vec_t v) {
   *reinterpret_cast<typename Elem<T>::vec_t*>(p) = v;
 }
+// non-temporal forms (the lines are marked for early eviction). Measured (tools/bench_gelu_after_gemm.py, gpurun_out/s2_gelu_nt.log): the GELU
+// backward — three [6280 x 15360] streams — 107 -> 90 us with both loads and the store non-temporal (95 with the loads only), -1 ms per step
+// (A B A B: 312.8 / 312.2 vs 311.2 / 311.7); the forward (two streams) 67 -> 72 us: not used there; silu_mul_bwd and adamw_k: no change.
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::vec_t ldv_nt(const T* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const typename Elem<T>::vec_t*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void stv_nt(T* p, typename Elem<T>::vec_t v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<typename Elem<T>::vec_t*>(p));
+}
 
 // ---------------------------------------------------------------- RMSNorm
 template <typename T>
@@ -359,13 +370,13 @@ __global__ __launch_bounds__(512) void gelu_tab_k(const unsigned short* __restri
   const float* tg = reinterpret_cast<const float*>(tab_raw);
   const int64_t nv = n / 8;
   for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 512) {
-    const u16x8_t hv = ldv<unsigned short>(h + i * 8);
+    const u16x8_t hv = BWD ? ldv_nt<unsigned short>(h + i * 8) : ldv<unsigned short>(h + i * 8);
     u16x8_t dv;
-    if (BWD) dv = ldv<unsigned short>(dy + i * 8);
+    if (BWD) dv = ldv_nt<unsigned short>(dy + i * 8);
     u16x8_t o;
     if (BWD) gelu_tab_bwd8(tg, hv, dv, o);
     else gelu_tab_fwd8(tf, hv, o);
-    stv<unsigned short>(y + i * 8, o);
+    if (BWD) stv_nt<unsigned short>(y + i * 8, o); else stv<unsigned short>(y + i * 8, o);
   }
   for (int64_t i = nv * 8 + (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) {
     const float x = bf2f(h[i]);
