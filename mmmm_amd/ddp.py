@@ -32,6 +32,7 @@ from dataclasses import dataclass, field
 import torch
 import torch.distributed as dist
 
+from . import hip
 from .param import no_weight_decay
 
 
@@ -133,6 +134,7 @@ class _Bucket:
     launched: bool = False
     work: object = None
     streams: set = field(default_factory=set)     # device streams that produced gradients of this bucket in this step
+    last_stream: object = None                    # the stream added last (hip.current_stream_obj: one object per stream, compared with `is`)
 
 
 class BucketedGradAllReduce:
@@ -324,9 +326,12 @@ class BucketedGradAllReduce:
     def _note_stream(self, p: torch.Tensor):
         """a fused kernel accumulated into p.grad on the current stream (possibly one of several uses of p in this step)"""
         if p.is_cuda:
-            st = torch.cuda.current_stream(p.device)
-            self.buckets[self._bucket_of[id(p)]].streams.add(st)
-            self._step_streams.add(st)
+            st = hip.current_stream_obj(p.device)
+            b = self.buckets[self._bucket_of[id(p)]]
+            if st is not b.last_stream:            # (one cached object per stream: the common case — same stream as last time — adds nothing)
+                b.last_stream = st
+                b.streams.add(st)
+                self._step_streams.add(st)
 
     def _mark_ready(self, p: torch.Tensor):
         """autograd has finished p's AccumulateGrad node: every use of p has reported, the slot is final"""
@@ -342,9 +347,11 @@ class BucketedGradAllReduce:
         b = self.buckets[self._bucket_of[id(p)]]
         b.pending -= 1
         if p.is_cuda:       # backward nodes run on the stream of their forward (the grounding heads use a side stream)
-            st = torch.cuda.current_stream(p.device)
-            b.streams.add(st)
-            self._step_streams.add(st)
+            st = hip.current_stream_obj(p.device)
+            if st is not b.last_stream:
+                b.last_stream = st
+                b.streams.add(st)
+                self._step_streams.add(st)
         self._launch_ready()
 
     def _launch(self, b: _Bucket, by_finish: bool = False):
@@ -358,6 +365,7 @@ class BucketedGradAllReduce:
                 if st != cur:
                     cur.wait_stream(st)
             b.streams.clear()
+            b.last_stream = None
             self._step_streams.add(cur)
             self._fold_f32(self.buckets.index(b))
         if self.collectives:
@@ -405,6 +413,8 @@ class BucketedGradAllReduce:
             if st != consumer:
                 consumer.wait_stream(st)
         self._step_streams.clear()
+        for b in self.buckets:
+            b.last_stream = None
         if self.collectives and self.world_size > 1:
             if self.defer_average:
                 # the buckets hold the SUM over ranks; whoever reads them next folds 1/world into a pass it makes anyway
@@ -440,6 +450,7 @@ class BucketedGradAllReduce:
             b.pending = len(b.params)
             b.launched = False
             b.streams.clear()
+            b.last_stream = None
             for p in b.params:
                 if p.grad is None or p.grad.data_ptr() < b.buffer.data_ptr() or \
                         p.grad.data_ptr() >= b.buffer.data_ptr() + b.buffer.numel() * b.buffer.element_size():

@@ -12,10 +12,30 @@ from dataclasses import dataclass
 
 import torch
 from torch.autograd import Function
-from torch.autograd.function import once_differentiable
 
 from . import hip
 from . import kernels as K
+
+
+def once_differentiable(fn):
+    """The kernels' backward passes are not differentiable again. torch's decorator of this name wraps EVERY backward call in a no_grad
+    context and an output check (~3 us x ~1 200 nodes per step on autograd's thread); the engine already runs backward with grad mode
+    off unless create_graph=True — so the only case to catch is that one, and it is an error here."""
+    def backward(ctx, *grads):
+        if torch.is_grad_enabled():
+            raise RuntimeError('the VividMed HIP operators are once differentiable: backward under create_graph=True is not supported')
+        return fn(ctx, *grads)
+    backward.__name__ = getattr(fn, '__name__', 'backward')
+    backward.__doc__ = fn.__doc__
+    return backward
+
+
+def _direct(cls):
+    """`cls.call` = the C++ `apply` of the autograd Function without `Function.apply`'s per-call functorch pass over the arguments
+    (`unwrap_dead_wrappers` + the setup_context probe: 8.2 -> 4.5 us per node, ~1 200 nodes per forward). No functorch transform is
+    ever active around these operators (they would have to trace raw device pointers)."""
+    cls.call = staticmethod(super(Function, cls).apply)
+    return cls
 
 
 _CU_CACHE: dict = {}
@@ -228,22 +248,24 @@ def _off_critical_path(fn, device, keep_alive):
 # of them, each too small for the chip alone. 0: one launch (+ its reduce launch) per factor as in round 2 (A/B measurements).
 WGRAD_GROUP = os.environ.get('VM_WGRAD_GROUP', '1') == '1'
 _WGRAD_QUEUE: list = []           # [(item for kernels.tn_skinny_group, param, ready callback)]
+_WGRAD_QUEUE_IDS: set = set()     # id() of the queued parameters (the queued entries keep them alive)
 _WGRAD_QUEUE_STATE = [None, None]     # graph-task id of the backward pass the queue belongs to, stream its operands were produced on
 
 
 def _queue_wgrad(param, ready, W, S, transpose_out, counts, seg, alpha, drop_p, seed):
     task = torch._C._current_graph_task_id()
-    st = torch.cuda.current_stream(W.device)
-    if task != _WGRAD_QUEUE_STATE[0] or st != _WGRAD_QUEUE_STATE[1]:
+    st = hip.current_stream_obj(W.device)            # (one cached object per stream: `is` instead of Stream.__eq__)
+    if task != _WGRAD_QUEUE_STATE[0] or st is not _WGRAD_QUEUE_STATE[1]:
         flush_wgrad_queue()
         if task != _WGRAD_QUEUE_STATE[0] and task >= 0:
             # whatever is still queued when this backward pass ends goes out then (callers may read .grad right after backward())
             torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_queue)
         _WGRAD_QUEUE_STATE[0], _WGRAD_QUEUE_STATE[1] = task, st
-    if any(q[1] is param for q in _WGRAD_QUEUE):
+    if id(param) in _WGRAD_QUEUE_IDS:
         # the same slot twice in one grouped launch (a LoRA linear applied twice within 24 queued factors: shared modules, depth-1 models):
         # two workgroups would read-modify-write one tile unsynchronised — the earlier items go out first
         flush_wgrad_queue()
+    _WGRAD_QUEUE_IDS.add(id(param))
     _WGRAD_QUEUE.append(((W, S, param.grad, transpose_out, counts, seg, alpha, drop_p, seed), param, ready))
     if len(_WGRAD_QUEUE) >= hip.TN_GROUP_MAX:
         flush_wgrad_queue()
@@ -256,16 +278,17 @@ def flush_wgrad_queue():
         return
     items = _WGRAD_QUEUE[:]
     _WGRAD_QUEUE.clear()
+    _WGRAD_QUEUE_IDS.clear()
     st = _WGRAD_QUEUE_STATE[1]
-    cur = torch.cuda.current_stream(st.device)
-    if cur != st:
+    cur = hip.current_stream_obj(st.device)
+    if cur is not st:
         torch.cuda.set_stream(st)
     try:
         K.tn_skinny_group([it for it, _, _ in items])
         for _, p, ready in items:
             ready(p)
     finally:
-        if cur != st:
+        if cur is not st:
             torch.cuda.set_stream(cur)
 
 
@@ -341,6 +364,7 @@ def _lora_wgrad_pair(params, W, S, transpose_out, counts, scale, drop_p, seed):
                        out_dtype=p0.dtype)
 
 
+@_direct
 class _Linear(Function):
     """y = act(x W^T + s·(drop(x) A^T) B^T + b) + residual, optionally per row segment.
 
@@ -520,7 +544,7 @@ def linear(x, W0, *, meta: LinearMeta | None = None, Wt0=None, b0=None, A0=None,
     meta = meta or LinearMeta()
     if _HELD_BY_TASK:
         _drop_stale_held()
-    return _Linear.apply(meta, x, residual, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
+    return _Linear.call(meta, x, residual, counts, W0, Wt0, b0, A0, B0, W1, Wt1, b1, A1, B1)
 
 
 # ----------------------------------------------------------------------------- norms
@@ -549,6 +573,7 @@ def _norm_params_off_path(params, run_kernel, keep_alive):
     return True
 
 
+@_direct
 class _RMSNorm(Function):
     """`fork`: also return x itself (a view) — the residual branch of a pre-norm block takes THAT, so both gradients of x arrive
     here and the kernel sums them (`dx_add`) instead of autograd adding them with one more pass over the activations"""
@@ -578,10 +603,11 @@ class _RMSNorm(Function):
 def rms_norm(x, w, eps: float, nrows=None, fork: bool = False):
     """`fork`: -> (y, x passed through) — use the second output as the block's residual"""
     if fork and not FORK:
-        return _RMSNorm.apply(x, w, eps, nrows, False), x
-    return _RMSNorm.apply(x, w, eps, nrows, fork)
+        return _RMSNorm.call(x, w, eps, nrows, False), x
+    return _RMSNorm.call(x, w, eps, nrows, fork)
 
 
+@_direct
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, w, b, eps, residual, fork=False):
@@ -617,11 +643,12 @@ class _LayerNorm(Function):
 def layer_norm(x, w, b, eps: float = 1e-5, residual=None, fork: bool = False):
     """residual + LayerNorm(x) (residual optional); `fork`: -> (y, x passed through) for a pre-norm block's residual"""
     if fork and not FORK:
-        return _LayerNorm.apply(x, w, b, eps, residual, False), x
-    return _LayerNorm.apply(x, w, b, eps, residual, fork)
+        return _LayerNorm.call(x, w, b, eps, residual, False), x
+    return _LayerNorm.call(x, w, b, eps, residual, fork)
 
 
 # ----------------------------------------------------------------------------- activations
+@_direct
 class _SiluMul(Function):
     @staticmethod
     def forward(ctx, gate, up):
@@ -636,9 +663,10 @@ class _SiluMul(Function):
 
 
 def silu_mul(gate, up):
-    return _SiluMul.apply(gate, up)
+    return _SiluMul.call(gate, up)
 
 
+@_direct
 class _Gelu(Function):
     @staticmethod
     def forward(ctx, x):
@@ -653,9 +681,10 @@ class _Gelu(Function):
 
 
 def gelu(x):
-    return _Gelu.apply(x)
+    return _Gelu.call(x)
 
 
+@_direct
 class _Relu(Function):
     """relu applied by the GEMM epilogue is not differentiable there; this is the standalone op"""
     @staticmethod
@@ -672,10 +701,11 @@ class _Relu(Function):
 
 
 def relu(x):
-    return _Relu.apply(x)
+    return _Relu.call(x)
 
 
 # ----------------------------------------------------------------------------- RoPE (in place on the packed qkv buffer)
+@_direct
 class _Rope(Function):
     @staticmethod
     def forward(ctx, qkv, row_pos, cos, sin, n_heads, head_dim, nrows):
@@ -695,10 +725,11 @@ class _Rope(Function):
 
 
 def rope_(qkv, row_pos, cos, sin, n_heads: int, head_dim: int, nrows=None):
-    return _Rope.apply(qkv, row_pos, cos, sin, n_heads, head_dim, nrows)
+    return _Rope.call(qkv, row_pos, cos, sin, n_heads, head_dim, nrows)
 
 
 # ----------------------------------------------------------------------------- var-len attention (bf16)
+@_direct
 class _Attention(Function):
     """`rope` = (row_pos, cos, sin, nrows): q and k are rotated IN PLACE on the packed qkv buffer before the attention (the standalone
     `_Rope` node's job) and the inverse rotation is applied in place to this node's own dqkv in the backward — no copy of the incoming
@@ -743,11 +774,12 @@ def attention(qkv, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, sca
     """qkv: [rows, 3*H*hd] packed (q | k | v) -> [rows, H*hd]. `rope` = (row_pos, cos, sin, nrows): rotate q / k in place first (and
     un-rotate the gradient in the backward) — `rope_` + `attention` in one autograd node"""
     if rope is not None:
-        return _Attention.apply(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, tuple(rope))[0]
-    return _Attention.apply(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
+        return _Attention.call(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, tuple(rope))[0]
+    return _Attention.call(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
 
 
 # ----------------------------------------------------------------------------- fp32 attention (SAM islands)
+@_direct
 class _AttentionF32(Function):
     @staticmethod
     def forward(ctx, q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen):
@@ -766,6 +798,7 @@ class _AttentionF32(Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+@_direct
 class _SelfAttentionF32(Function):
     """fp32 self-attention on a packed qkv [T, 3*H*hd] (SAM ViT-B, image_encoder.py:126-136): q/k/v are strided views in
     both directions and the gradient is ONE dqkv tensor written in place by the kernels — no contiguous copies of the
@@ -795,7 +828,7 @@ class _SelfAttentionF32(Function):
 def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen, f32_split: int = 0):
     """`f32_split` (head_dim 64): arithmetic of the attention products — 0 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products
     (kernels.attn_f32_fwd); the image encoders pass their blocks' `f32_split` (image_encoder.ENCODER_F32_SPLIT)"""
-    return _SelfAttentionF32.apply(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split)
+    return _SelfAttentionF32.call(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split)
 
 
 _F32_HEAD_DIMS = (8, 16, 32, 48, 64, 96, 128)       # instantiations of attn_f32_*_k (csrc/attn_f32.hip)
@@ -811,12 +844,13 @@ def attention_f32(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens
 
         def pad(t):
             return torch.nn.functional.pad(t.reshape(*t.shape[:-1], n_heads, head_dim), (0, hp - head_dim)).reshape(*t.shape[:-1], n_heads * hp)
-        out = _AttentionF32.apply(pad(q), pad(k), pad(v), n_heads, hp, scale, cu_seqlens, max_seqlen)
+        out = _AttentionF32.call(pad(q), pad(k), pad(v), n_heads, hp, scale, cu_seqlens, max_seqlen)
         return out.reshape(*out.shape[:-1], n_heads, hp)[..., :head_dim].reshape(*out.shape[:-1], n_heads * head_dim)
-    return _AttentionF32.apply(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
+    return _AttentionF32.call(q, k, v, n_heads, head_dim, scale, cu_seqlens, max_seqlen)
 
 
 # ----------------------------------------------------------------------------- rows: embedding / gather / scatter
+@_direct
 class _EmbeddingRows(Function):
     """out[r] = weight[ids[r]] (ids < 0 -> zeros); weight gradient by the segmented-sum kernel"""
     @staticmethod
@@ -836,9 +870,10 @@ class _EmbeddingRows(Function):
 
 
 def embedding_rows(weight, ids):
-    return _EmbeddingRows.apply(weight, ids)
+    return _EmbeddingRows.call(weight, ids)
 
 
+@_direct
 class _GatherRows(Function):
     @staticmethod
     def forward(ctx, src, idx, nrows_out):
@@ -857,9 +892,10 @@ class _GatherRows(Function):
 
 def gather_rows(src, idx, nrows_out: int | None = None):
     """out[r] = src[idx[r]]; idx must not repeat a source row (permutation-like maps)"""
-    return _GatherRows.apply(src, idx, nrows_out)
+    return _GatherRows.call(src, idx, nrows_out)
 
 
+@_direct
 class _OverwriteRows(Function):
     """base[idx[r]] = src[r] in place (image features into the embedded sequence, modeling_cogvlm.py:451-453)"""
     @staticmethod
@@ -880,12 +916,13 @@ class _OverwriteRows(Function):
 
 
 def overwrite_rows_(base, src, idx):
-    return _OverwriteRows.apply(base, src, idx)
+    return _OverwriteRows.call(base, src, idx)
 
 
 # ----------------------------------------------------------------------------- trilinear up-sampling of mask logits
 
 
+@_direct
 class _UpsampleTrilinear(Function):
     @staticmethod
     def forward(ctx, x, size):
@@ -907,11 +944,12 @@ def upsample_trilinear(x: torch.Tensor, size) -> torch.Tensor:
     lead = x.shape[:-3]
     if x.numel() == 0:                         # no prompts: nothing to interpolate, the result is empty too
         return x.new_zeros(*lead, *size) + 0 * x.sum()
-    y = _UpsampleTrilinear.apply(x.reshape(-1, *x.shape[-3:]).contiguous(), size)
+    y = _UpsampleTrilinear.call(x.reshape(-1, *x.shape[-3:]).contiguous(), size)
     return y.view(*lead, *size)
 
 
 # ----------------------------------------------------------------------------- Dice + focal loss of mask logits
+@_direct
 class _DiceFocal(Function):
     """per-row Dice loss and per-row SUM of the sigmoid-focal loss of fp32 mask logits (mmmm/models/loss.py:32-56) in one
     streaming pass each way instead of ~40 element-wise / reduction launches"""
@@ -934,10 +972,11 @@ class _DiceFocal(Function):
 
 def dice_focal(x, target, gamma: float, alpha: float | None):
     """x fp32 [R, n] logits, target uint8 [R, n] | None -> (dice [R], focal_sum [R])"""
-    return _DiceFocal.apply(x, target, gamma, alpha)
+    return _DiceFocal.call(x, target, gamma, alpha)
 
 
 # ----------------------------------------------------------------------------- hyper-network mask product (SAM mask decoder)
+@_direct
 class _InstanceLoss(Function):
     """the instance losses of one sample in one launch each way (kernels.instance_loss_fwd / _bwd)"""
 
@@ -960,9 +999,10 @@ def instance_loss(logit, reg, label, match, gamma: float, alpha: float | None):
     """logit fp32 [nt, nq], reg fp32 [nt, 1 + nq, 6], label fp32 [n_boxes, 6], match int64 [nt, nq] (matched label box | < 0)
     -> fp32 [6] = (focal mean over all entries, focal mean matched vs 1 [log], focal mean unmatched vs 0 [log], l1 mean of matched
     pairs, 1 - mean GIoU of matched pairs, matched count); gradients flow to logit and reg through entries 0, 3, 4"""
-    return _InstanceLoss.apply(logit, reg, label, match, gamma, alpha)
+    return _InstanceLoss.call(logit, reg, label, match, gamma, alpha)
 
 
+@_direct
 class _HyperProduct(Function):
     """y[p] = up[p] @ w[p]^T for every prompt p: up [P, V, C] fp32 (up-scaled image embedding per prompt, channel-last), w [P, M, C]
     (per-prompt hyper-network weights) -> y [P, V, M]. Reference mask_decoder.py:139-147 (`einsum('n m c, n c ... -> n m ...')`).
@@ -1004,10 +1044,11 @@ class _HyperProduct(Function):
 
 
 def hyper_product(up, w):
-    return _HyperProduct.apply(up, w)
+    return _HyperProduct.call(up, w)
 
 
 # ----------------------------------------------------------------------------- weighted CE over the vocabulary
+@_direct
 class _WeightedCE(Function):
     """loss = sum_r ce_r * w_r / n_valid  (modeling_cogvlm.py:610-627); also returns the per-row CE (no grad)."""
     @staticmethod
@@ -1031,10 +1072,11 @@ class _WeightedCE(Function):
 
 
 def weighted_ce(logits, labels, weight, vocab: int, nrows=None):
-    return _WeightedCE.apply(logits, labels, weight, vocab, nrows)
+    return _WeightedCE.call(logits, labels, weight, vocab, nrows)
 
 
 # ----------------------------------------------------------------------------- patch embedding
+@_direct
 class _Im2Col(Function):
     """[C,D,H,W] image -> [n_patch, C*pz*py*px] (no gradient to the image: inputs are data)"""
     @staticmethod
@@ -1047,4 +1089,4 @@ class _Im2Col(Function):
 
 
 def im2col3d(image, patch):
-    return _Im2Col.apply(image, tuple(patch))
+    return _Im2Col.call(image, tuple(patch))

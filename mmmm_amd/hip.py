@@ -196,6 +196,23 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_STREAM_OBJ: dict = {}
+
+
+def current_stream_obj(device=None) -> 'torch.cuda.Stream':
+    """torch's current stream on `device` as a torch.cuda.Stream — the SAME object for the same stream every time, so callers may compare
+    with `is` and skip set insertions. `torch.cuda.current_stream()` builds a new wrapper per call (~4 us) and its __eq__ / __hash__ are
+    Python: the backward pass asked ~5k times per step (22 ms of host time under cProfile, profiles/r5_host_profile_v2.txt)."""
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    if _raw_stream is None:
+        return torch.cuda.current_stream(idx)
+    key = (idx, _raw_stream(idx))
+    st = _STREAM_OBJ.get(key)
+    if st is None:
+        st = _STREAM_OBJ[key] = torch.cuda.current_stream(idx)
+    return st
+
+
 _fns: dict = {}
 
 

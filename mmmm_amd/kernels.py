@@ -23,8 +23,9 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 def _ld(t: torch.Tensor) -> int:
     """leading dimension (elements) of a 2-D row-major view with unit inner stride"""
-    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
-    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    st = t.stride()              # (one call: this runs ~13k times per step)
+    assert len(st) == 2 and st[1] == 1, (t.shape, st)
+    return st[0] if t.shape[0] > 1 else max(st[0], t.shape[1])
 
 
 # ------------------------------------------------------------------ GEMM
