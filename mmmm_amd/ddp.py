@@ -137,6 +137,33 @@ class _Bucket:
     last_stream: object = None                    # the stream added last (hip.current_stream_obj: one object per stream, compared with `is`)
 
 
+_POST_HOOK_ON_NONE: list = []
+
+
+def _post_hook_fires_on_none() -> bool:
+    """Does this torch run a parameter's post-accumulate-grad hook when every use handed back None (the fused kernels accumulate
+    straight into the bucket view)? A three-element CPU experiment, once per process."""
+    if not _POST_HOOK_ON_NONE:
+        class _Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x * 2
+
+            @staticmethod
+            def backward(ctx, g):
+                return g * 2, None
+
+        fired = []
+        with torch.enable_grad():
+            w = torch.nn.Parameter(torch.ones(3))
+            x = torch.ones(3, requires_grad=True)
+            h = w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+            _Probe.apply(x, w).sum().backward()
+            h.remove()
+        _POST_HOOK_ON_NONE.append(bool(fired))
+    return _POST_HOOK_ON_NONE[0]
+
+
 class BucketedGradAllReduce:
     """Readiness protocol. A slot is READY when autograd has finished the parameter's AccumulateGrad node, which the engine
     runs exactly once per backward pass, after EVERY use of the parameter has run its backward — also when all of them
@@ -186,11 +213,14 @@ class BucketedGradAllReduce:
         assert torch.is_grad_enabled(), 'BucketedGradAllReduce must be built with autograd enabled (it hooks the AccumulateGrad nodes)'
         if self.world_size > 1 and sync_params:
             self.sync_parameters()
+        need_prehook = not _post_hook_fires_on_none()
         for p in self.params:
             acc = p.view_as(p).grad_fn.next_functions[0][0]
             self._acc_nodes.append(acc)
-            # every use returned None (direct accumulation): older engines skip the post-accumulate hook then
-            self._hooks.append(acc.register_prehook(lambda grads, p=p: self._mark_ready(p) if grads[0] is None else None))
+            if need_prehook:
+                # every use returned None (direct accumulation): older engines skip the post-accumulate hook then. (Probed once per
+                # process: where the post hook fires anyway the prehook would only double the ~1 800 Python calls per backward pass.)
+                self._hooks.append(acc.register_prehook(lambda grads, p=p: self._mark_ready(p) if grads[0] is None else None))
             self._hooks.append(p.register_post_accumulate_grad_hook(self._mark_ready))
             p._vm_grad_ready = self._note_stream
             if p.dtype == torch.bfloat16 and p.is_cuda:
