@@ -57,6 +57,7 @@ struct DownP {
 // not latency-bound; only a cheaper hash would help, and the hash is shared with the oracle and every other consumer of the mask.
 constexpr int DN_BM = 64;
 
+template <int AUX = 0>
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
                                            int col0, int cols_total, char* tile, int wave, int lane);
 
@@ -243,6 +244,7 @@ struct TnP {
 
 // stage 32 rows x 128 bf16 columns (256 B per row) of a row-major operand: LDS image is lane-linear, the swizzle is
 // applied to the SOURCE chunk (rule 21); rows / columns outside the operand read as zero (buffer bounds + ld check)
+template <int AUX>
 __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t ld, int row_begin, int rows_valid,
                                            int col0, int cols_total, char* tile, int wave, int lane) {
   // the buffer covers rows [row_begin, row_begin + rows_valid); per-lane offset = r * ld*2 + col bytes
@@ -257,7 +259,7 @@ __device__ __forceinline__ void stage_rows(const unsigned short* base, int64_t l
     const int col = col0 + chunk * 8;
     // columns past the operand width must read zero: push the offset out of the buffer
     const int voff = (col + 8 <= cols_total) ? row * ld_b + col * 2 : 0x7FFFFFF0;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + inst * 1024), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + inst * 1024), 16, voff, 0, 0, AUX);
   }
 }
 
@@ -729,8 +731,10 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
     const int r0 = rb + step * 32;
     const int valid = step < steps ? min(32, re - r0) : 0;
     char* sw = smem + buf * GR_STAGE_BYTES;
-    stage_rows(W, q.ldw, r0, valid, c0, C, sw, wave, lane);
-    stage_rows(W, q.ldw, r0, valid, c0 + 128, C, sw + 32 * ROWB, wave, lane);
+    // (W = the layer's activations or output gradients, read here for the last time in the step: non-temporal LDS-DMA (aux 2) —
+    // 304.2 / 304.15 vs 303.6 / 303.95 ms per step, A B A B, gpurun_out/s2_ab_tnnt.log; S is re-read by every workgroup: default policy)
+    stage_rows<2>(W, q.ldw, r0, valid, c0, C, sw, wave, lane);
+    stage_rows<2>(W, q.ldw, r0, valid, c0 + 128, C, sw + 32 * ROWB, wave, lane);
     stage_rows(S, q.lds, r0, valid, 0, 64, sw + 2 * 32 * ROWB, wave, lane);
   };
   const bool drop = q.drop_p > 0.f;
