@@ -375,6 +375,28 @@ def dry_run_cpu(args, rank: int, world: int):
         dist.destroy_process_group()
 
 
+def apply_sets(sets) -> bool:
+    """--set MODULE.NAME=VALUE: module-level constants of mmmm_amd for A/B measurements (python literals). Returns whether
+    functional.WGRAD_SIDE_STREAM was among them (the calibration then leaves it alone)."""
+    import ast
+    import importlib
+    forced = False
+    for item in sets:
+        path, _, val = item.partition('=')
+        mod, _, name = path.rpartition('.')
+        m = importlib.import_module('mmmm_amd.' + mod)
+        if not hasattr(m, name):
+            raise SystemExit(f'--set {item}: mmmm_amd.{mod} has no attribute {name}')
+        setattr(m, name, ast.literal_eval(val))
+        forced = forced or (mod == 'functional' and name == 'WGRAD_SIDE_STREAM')
+    return forced
+
+
+def _enc_split() -> int:
+    from mmmm_amd.models.segvol.modeling import image_encoder
+    return image_encoder.ENCODER_F32_SPLIT
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -382,10 +404,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--hbm-fraction', type=float, default=0.76,
                     help='--checkpointing hbm: reserved-memory target of the calibration steps (the pool settles ~10 %% of the HBM above it)')
-    ap.add_argument('--workload', default=os.environ.get('VM_WORKLOAD', 'phase-vg-448'), choices=list(WORKLOADS))
+    ap.add_argument('--workload', default='phase-vg-448', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=8, help='samples per GPU')
     ap.add_argument('--depth-scale', type=float, default=1.0, help='debug only: <1 shrinks depth and invalidates the number')
-    ap.add_argument('--checkpointing', default=os.environ.get('VM_CHECKPOINTING', 'hbm'), choices=['hbm', 'reference'],
+    ap.add_argument('--checkpointing', default='hbm', choices=['hbm', 'reference'],
                     help="'reference': recompute every transformer layer in backward (mmmm.py:232-233); 'hbm': keep the "
                          "activations of as many layers as the free HBM of this device holds (same results, less recompute)")
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
@@ -405,11 +427,18 @@ def main():
     ap.add_argument('--no-calibrate', action='store_true',
                     help='counter-collection runs only (tools/pmc_step.sh): keep the planning step but skip the calibration steps that follow it')
     ap.add_argument('--no-peak-probe', action='store_true', help='skip the 2 s MFMA peak measurement (roofline.peak_measured)')
-    ap.add_argument('--also-budget', type=float, default=float(os.environ.get('VM_BENCH_ALSO_BUDGET', '330')),
+    ap.add_argument('--also-budget', type=float, default=330.0,
                     help='seconds of wall clock for the --also children together: a child is only started while the budget lasts (the rest are reported as skipped)')
-    ap.add_argument('--also', default=os.environ.get('VM_BENCH_ALSO', 'phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8,model-hr-3d'),
+    ap.add_argument('--also', default='phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8,model-hr-3d',
                     help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
                          "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
+    ap.add_argument('--set', action='append', default=[], metavar='MODULE.NAME=VALUE',
+                    help="A/B measurements (tools/ab_set.sh): set a module-level constant of mmmm_amd before the model is built, e.g. "
+                         "functional.WGRAD_SIDE_STREAM=True, functional.NN_DGRAD=True, models.cogvlm.modeling_cogvlm.LM_HEAD_LABEL_ROWS=False. "
+                         "The product reads no environment switches; a number measured with --set is an experiment, not the benchmark")
+    ap.add_argument('--force-dist', action='store_true', help='one rank, but through the RCCL collectives (tests)')
+    ap.add_argument('--fwd-pool', action='store_true', help='experiment: forward allocations from a memory pool of their own')
+    ap.add_argument('--mem-summary', action='store_true', help='print the allocator summary after each calibration round')
     args = ap.parse_args()
 
     # N > 1 from a plain `python bench.py --gpus N`: start one fresh process per GPU through torch.distributed.run and pass its
@@ -431,7 +460,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the VividMed hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    use_dist = world > 1 or os.environ.get('VM_FORCE_DIST') == '1'      # VM_FORCE_DIST: exercise the RCCL path on one rank
+    use_dist = world > 1 or args.force_dist      # --force-dist: exercise the RCCL path on one rank
     if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -439,6 +468,7 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from mmmm_amd import kernels as K, hip
+    side_stream_forced = apply_sets(args.set)
     from mmmm_amd.ddp import BucketedGradAllReduce
     w = WORKLOADS[args.workload]
     model, tok = build(w, device, args.depth_scale)
@@ -461,7 +491,7 @@ def main():
     # workload draws new text lengths per batch, so sequence-length tables change from step to step as they do in training)
     batches = [make_batch(w, tok, args.batch, device, seed=1000 * rank + i) for i in range(max(1, args.batches))]
     it = [0]
-    fwd_pool = torch.cuda.MemPool() if os.environ.get('VM_FWD_POOL', '0') == '1' else None
+    fwd_pool = torch.cuda.MemPool() if args.fwd_pool else None
 
     def step():
         batch = batches[it[0] % len(batches)]
@@ -484,7 +514,7 @@ def main():
     from mmmm_amd.models.lora import ActivationBudget
     plan = 'every layer recomputed'
     import mmmm_amd.functional as Fh
-    side_stream_note = ['on' if Fh.WGRAD_SIDE_STREAM else 'off (VM_WGRAD_STREAM=0)']
+    side_stream_note = ['on' if Fh.WGRAD_SIDE_STREAM else 'off (functional.WGRAD_SIDE_STREAM)']
     if args.checkpointing == 'hbm':
         # planning step (untimed, not a warmup step): peak HBM with every layer checkpointed -> what is left over
         # becomes the activation budget of the following steps
@@ -530,12 +560,12 @@ def main():
                 r1 = int(t.item())
             if rank == 0:
                 print(f'[calibrate] budget {ActivationBudget.limit / 2**30:.1f} GB kept {ActivationBudget.last_plan}: reserved {r1 / 2**30:.1f} GB, allocated peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB (target {target / 2**30:.0f} GB)', file=sys.stderr)
-            if rank == 0 and os.environ.get('VM_MEM_SUMMARY') == '1':
+            if rank == 0 and args.mem_summary:
                 print(torch.cuda.memory_summary(abbreviated=True), file=sys.stderr)
             if r1 <= target + (4 << 30) or ActivationBudget.limit == 0:
                 break
             import mmmm_amd.functional as Fh
-            if Fh.WGRAD_SIDE_STREAM and os.environ.get('VM_WGRAD_STREAM') is None:
+            if Fh.WGRAD_SIDE_STREAM and not side_stream_forced:
                 # First resort: give up the weight-gradient side stream instead of kept layers. Every tensor its kernels read is
                 # withheld from the allocator until that stream has passed it, and the stream owns a block pool of its own: on the
                 # large workloads the pool then holds 50-90 GB more than is ever allocated (phase-grg-3d: reserved 244 GB for an
@@ -613,7 +643,7 @@ def main():
             'vs_baseline': None, 'dtype': 'fp8-e4m3 frozen-weight GEMMs (fwd + dgrad), bf16 elsewhere' if args.fp8 else 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (VM_ENC_F32_SPLIT=%s)' % os.environ.get('VM_ENC_F32_SPLIT', '2')) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (image_encoder.ENCODER_F32_SPLIT = %d)' % _enc_split()) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
             'loss': loss_v,
             'host_enqueue_ms': min(host_enq),
             'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min of 2 untimed steps after the timed region); must stay below ms_per_step',

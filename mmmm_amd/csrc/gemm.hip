@@ -566,15 +566,18 @@ static int& sk_mode() { static int mode = 0; return mode; }
 extern "C" int vm_gemm_sched_mode_(int mode) { if (mode < 0 || mode > 2) return VM_ERR_BAD_ARG; sk_mode() = mode; return VM_OK; }
 static unsigned sk_next_epoch() { static std::atomic<unsigned> e{0}; unsigned v; do { v = ++e; } while (v == 0); return v; }
 
-// VM_GEMM_TILE=128|192|256 forces the one-tile-per-workgroup kernel with that tile, -192 removes the 192-row form from the choice
-// (tests / A-B measurements). `kt` = K-tiles per output tile (extension included), `tk` = us per K-tile of the 256-row body.
+// vm_gemm_force_tile_(128|192|256) forces the one-tile-per-workgroup kernel with that tile, -192 removes the 192-row form from the choice,
+// 0 gives the choice back to the cost model (tests / A-B measurements). `kt` = K-tiles per output tile (extension included), `tk` = us per
+// K-tile of the 256-row body.
 constexpr double SK_C_SEG = 7.5, SK_C_FIX = 9.0, SK_T_K_BF16 = 1.42, SK_T_K_F8 = 2.0;
+static int& forced_tile() { static int t = 0; return t; }
+extern "C" int vm_gemm_force_tile_(int tile) {
+  if (tile != 0 && tile != 128 && tile != 192 && tile != 256 && tile != -192) return VM_ERR_BAD_ARG;
+  forced_tile() = tile;
+  return VM_OK;
+}
 static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool sk_ok) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("VM_GEMM_TILE");
-    forced = e ? atoi(e) : 0;
-  }
+  const int forced = forced_tile();
   if (forced == 128) return {0, 0};
   if (forced == 256 || forced == 192) return {1, forced};
   if (kt < 2) return {0, 0};
@@ -602,7 +605,7 @@ static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool s
 
 // fp32 GEMM arithmetic: 0 = exact f32 MFMA, 2 = split-bf16 with 3 products, 3 = split-bf16 with 6 products (default: fp32 products).
 static int& f32_mode() {
-  static int mode = [] { const char* e = getenv("VM_F32_SPLIT"); const int v = e ? atoi(e) : 3; return (v == 0 || v == 2 || v == 3) ? v : 3; }();
+  static int mode = 3;
   return mode;
 }
 

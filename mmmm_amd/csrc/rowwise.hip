@@ -821,10 +821,9 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
   else return VM_ERR_BAD_ARG;
 
 // bf16 tensors of >= 1 M elements go through the table kernels
-static bool gelu_use_table(int64_t n, int dtype) {      // VM_GELU_TABLE=0: always the arithmetic kernel
-  static const int on = [] { const char* e = getenv("VM_GELU_TABLE"); return e ? atoi(e) : 1; }();
-  return on && dtype == VM_BF16 && n >= (1 << 20);
-}
+static int& gelu_table_on() { static int on = 1; return on; }
+extern "C" int vm_gelu_table_(int on) { gelu_table_on() = on ? 1 : 0; return VM_OK; }      // internal (tools/bench_gelu.py): 0 = always the arithmetic kernel
+static bool gelu_use_table(int64_t n, int dtype) { return gelu_table_on() && dtype == VM_BF16 && n >= (1 << 20); }
 template <bool BWD>
 static int gelu_tab_launch(const void* x, const void* dy, void* y, int64_t n, void* stream) {
   if (!aligned16(x) || !aligned16(y) || (BWD && !aligned16(dy))) return VM_ERR_BAD_ARG;

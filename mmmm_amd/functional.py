@@ -6,7 +6,6 @@ libvividmed_hip.so; there is no eager/PyTorch fallback (a CPU tensor raises in m
 """
 from __future__ import annotations
 
-import os
 import weakref
 from dataclasses import dataclass
 
@@ -132,7 +131,7 @@ def _lora_project(x, A0, A1, gated, counts, drop_p=0.0, seed=0):
 
 _WGRAD_STREAMS: dict = {}
 _WGRAD_EVENTS: dict = {}
-SIDE_LAG = int(os.environ.get('VM_SIDE_LAG', '24'))          # forked calls the side stream may trail the main stream by (~2 transformer layers)
+SIDE_LAG = 24          # forked calls the side stream may trail the main stream by (~2 transformer layers)
 
 
 _HELD_BY_TASK: dict = {}     # graph-task id -> tensors held until that backward pass ends
@@ -187,22 +186,22 @@ def abort_backward_state():
 # [r3] OFF by default: with the chip saturated by the main stream the side stream no longer hides anything (round 2 already measured
 # 334.3 vs 334.9 ms) and, now that the LoRA factor gradients go out as grouped launches on the main stream, it costs time:
 # 329.9 (on) vs 325.8 / 325.3 ms (off), A B A in one call. It also withholds memory from the caching allocator.
-WGRAD_SIDE_STREAM = os.environ.get('VM_WGRAD_STREAM', '0') == '1'
+WGRAD_SIDE_STREAM = False      # (module constants, not environment switches: tests and `bench.py --set functional.NAME=value` flip them)
 # 1: dgrad reads the weight as stored (`b_nn` form of the 256-column GEMM) and no transposed copies of the frozen weights are kept
 # (-35 GB). Bit-identical to the NT form but currently 0.6-0.85x its rate (192-row tiles only, 64-byte DMA segments, twice the LDS
 # read instructions): the step loses more than the freed memory buys (model-hr-3d: every layer kept, yet 3.47 vs 3.59 images/s;
 # phase-vg-448 445 vs 359 ms), so the default stays the NT dgrad on resident transposes.
-NN_DGRAD = os.environ.get('VM_NN_DGRAD', '0') == '1'
+NN_DGRAD = False
 # fp32 weight gradients of the unfrozen heads through the TN kernel (vm_gemm_tn_f32: no transposed copies of dy and x); 0: round 2's
 # two transposes + NT GEMM (A/B measurements)
-F32_TN_WGRAD = os.environ.get('VM_F32_TN_WGRAD', '1') == '1'
+F32_TN_WGRAD = True
 # 0: ops asked to `fork` (hand their input back for the block's residual) return the input itself, i.e. autograd sums the two gradients of
 # the input with its own element-wise add (A/B measurements)
-FORK = os.environ.get('VM_FORK', '1') == '1'
+FORK = True
 # the LINEAR form of the fork (post-norm ViT-E blocks: the residual's gradient rides in the dgrad GEMM's epilogue) is off by default: it
 # removes 126 element-wise adds per step but makes 126 dgrad GEMMs read one more [tokens, hidden] operand — step time equal
-# (342.4 vs 342.8 ms), dominant-GEMM rate 1 164 vs 1 178 TFLOP/s (A B A B in one call). VM_FORK_LINEAR=1 turns it on.
-FORK_LINEAR = FORK and os.environ.get('VM_FORK_LINEAR', '0') == '1'
+# (342.4 vs 342.8 ms), dominant-GEMM rate 1 164 vs 1 178 TFLOP/s (A B A B in one call).
+FORK_LINEAR = False
 
 
 def _off_critical_path(fn, device, keep_alive):
@@ -246,7 +245,7 @@ def _off_critical_path(fn, device, keep_alive):
 # LoRA factor gradients are not launched one by one: they are queued and go out as ONE grouped launch per ~layer
 # (kernels.tn_skinny_group / vm_tn_skinny_group_bf16): a transformer layer's backward produces 8 (ViT-E) or 20 (decoder, two experts)
 # of them, each too small for the chip alone. 0: one launch (+ its reduce launch) per factor as in round 2 (A/B measurements).
-WGRAD_GROUP = os.environ.get('VM_WGRAD_GROUP', '1') == '1'
+WGRAD_GROUP = True
 _WGRAD_QUEUE: list = []           # [(item for kernels.tn_skinny_group, param, ready callback)]
 _WGRAD_QUEUE_IDS: set = set()     # id() of the queued parameters (the queued entries keep them alive)
 _WGRAD_QUEUE_STATE = [None, None]     # graph-task id of the backward pass the queue belongs to, stream its operands were produced on

@@ -213,15 +213,7 @@ def ubench_mfma_bf16(seconds: float = 2.0) -> float:
     return float(out.value)
 
 
-def _f32_mode_from_env() -> int:
-    try:
-        v = int(os.environ.get('VM_F32_SPLIT', '3'))
-    except ValueError:
-        v = 3
-    return v if v in (0, 2, 3) else 3
-
-
-_F32_MODE = [_f32_mode_from_env()]          # mirror of the library's process default (gemm.hip f32_mode(): same rule, same variable)
+_F32_MODE = [3]          # mirror of the library's process default (gemm.hip f32_mode(): six products); f32_mode() below changes both
 
 
 def gemm_f32_mode(mode: int):
@@ -610,9 +602,9 @@ def expert_index_build(token_type_ids: torch.Tensor, attention_mask: torch.Tenso
 # ------------------------------------------------------------------ attention (bf16, var-len)
 # The backward's dS^T scratch pays while the N x N matrix is cheap beside the recomputation it saves: measured 8 x 785 and 8 x 456 faster
 # (dQ 103 -> 47 us, 61 -> 31 us against +11 / +5 us on dK/dV), 8 x 2049 equal, 4 x 4609 slower — so the switch is the sequence length, and
-# the byte cap only bounds the transient allocation (VM_ATTN_DS_MAX_MB=0: always recompute)
-ATTN_DS_MAX_BYTES = int(os.environ.get('VM_ATTN_DS_MAX_MB', '4096')) << 20
-ATTN_DS_MAX_SEQLEN = int(os.environ.get('VM_ATTN_DS_MAX_SEQLEN', '1536'))
+# the byte cap only bounds the transient allocation (0: always recompute)
+ATTN_DS_MAX_BYTES = 4096 << 20
+ATTN_DS_MAX_SEQLEN = 1536
 def _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max):
     a = hip.AttnArgs()
     a.q, a.k, a.v, a.out = ptr(q), ptr(k), ptr(v), ptr(out)

@@ -305,7 +305,7 @@ class CogVLMModel(nn.Module):
         return x
 
 
-LM_HEAD_LABEL_ROWS = os.environ.get('VM_LMHEAD_LABEL_ROWS', '1') != '0'
+LM_HEAD_LABEL_ROWS = True
 
 
 class _LMHeadCE(torch.autograd.Function):

@@ -4,7 +4,6 @@ On the GPU (fp32 logits, boolean targets — what the training step passes) both
 and what the fused kernels are tested against."""
 from __future__ import annotations
 
-import os
 
 import torch
 from torch import nn
@@ -26,7 +25,7 @@ def sigmoid_focal_loss(x: torch.Tensor, y: torch.Tensor, gamma: float, alpha: fl
 
 
 class DiceFocalLoss(nn.Module):
-    fused = os.environ.get('VM_DICE_FUSED', '1') == '1'        # 0: element-wise torch form on the GPU as well (A/B measurements)
+    fused = True        # 0: element-wise torch form on the GPU as well (A/B measurements)
 
     def __init__(self, dice_weight: float, focal_weight: float, focal_gamma: float, focal_alpha: float | None = None):
         super().__init__()

@@ -148,7 +148,7 @@ class MMMMForCausalLM(CogVLMForCausalLM):
                   isam.mask_decoder.txt_align_upscaled_embedding):
             m.requires_grad_(False)
 
-    concurrent_heads: bool = os.environ.get('VM_CONCURRENT_HEADS', '1') == '1'      # SAM and iSAM on two HIP streams (visual_grounding)
+    concurrent_heads: bool = True      # SAM and iSAM on two HIP streams (visual_grounding)
 
     def get_fp32_children(self) -> list[str]:
         return ['sam', 'isam_model', 'vg_proj']

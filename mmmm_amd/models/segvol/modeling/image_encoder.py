@@ -3,7 +3,6 @@
 one var-len sequence; attention on vm_attn_*_f32 (head_dim 64)."""
 from __future__ import annotations
 
-import os
 
 import torch
 from torch import nn
@@ -15,9 +14,9 @@ from ...cogvlm.visual import ParameterWrapper
 from ...lora import Linear
 from ...resample import Downsample, resample
 
-ENCODER_F32_SPLIT = int(os.environ.get('VM_ENC_F32_SPLIT', '2'))
+ENCODER_F32_SPLIT = 2
 # arithmetic of the blocks' attention products (functional.self_attention_f32): -1 = the same as the blocks' GEMMs
-ATTN_F32_SPLIT = int(os.environ.get('VM_ATTN_F32_SPLIT', '-1'))
+ATTN_F32_SPLIT = -1
 
 
 class PatchEmbeddingBlock(nn.Module):

@@ -7,7 +7,6 @@ synchronises once per target, sam.py:243) and the instance losses of a sample ar
 CPU tensors take the reference's route (element-wise torch ops, SciPy on the host)."""
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 
 import torch
@@ -143,7 +142,7 @@ class InstanceSamLoss(nn.Module):
         self.box_l1_weight, self.box_giou_weight, self.disc_weight = box_l1_weight, box_giou_weight, disc_weight
         self.disc_focal_gamma, self.disc_focal_alpha = disc_focal_gamma, disc_focal_alpha
         self.match_ce = match_ce
-        self.fused = os.environ.get('VM_INSTANCE_LOSS_FUSED', '1') == '1'      # 0: element-wise torch form on the GPU as well (A/B, tests)
+        self.fused = True      # 0: element-wise torch form on the GPU as well (A/B, tests)
 
     def box_loss(self, input, target, reduce_batch: bool = True, return_dict: bool = False):
         l1 = F.l1_loss(input, target) if reduce_batch else F.l1_loss(input, target, reduction='none').mean(dim=-1)

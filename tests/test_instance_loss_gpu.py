@@ -76,7 +76,7 @@ def test_fused_instance_loss_equals_the_elementwise_form(dev, counts, nq, gamma,
     dummy = reg.new_empty((len(counts), 1 + nq, 0, 0, 0))
     res = []
     for fused in (True, False):
-        il.fused = fused                                    # (set per call: VM_INSTANCE_LOSS_FUSED only picks the default)
+        il.fused = fused                                    # (set per call)
         b, d = reg.clone().requires_grad_(), logit.clone().requires_grad_()
         loss, log = il.compute_loss(dummy, dummy, b, d, None, label, offs, match=match)
         (loss * 1.7).backward()

@@ -47,14 +47,15 @@ def test_gemm_bf16_plain(dev, K, M, N, K_):
 
 @pytest.mark.parametrize('tile', ['192', '256'])
 def test_gemm_bf16_suite_with_forced_big_tiles(dev, tile):
-    """the tile chooser picks the 256-row / 192-row big-tile kernels only for shapes that fill the chip; VM_GEMM_TILE (read
-    once per process) forces them, so the bf16 GEMM tests are re-run in a child process on every small / ragged shape too"""
+    """the tile chooser picks the 256-row / 192-row big-tile kernels only for shapes that fill the chip; `vm_gemm_force_tile_` (called by
+    the `dev` fixture of the child run, tests/conftest.py) forces them, so the bf16 GEMM tests are re-run in a child process on every
+    small / ragged shape too"""
     import os
     import subprocess
     import sys
     if os.environ.get('VM_TEST_CHILD'):
         pytest.skip('already inside the forced-tile child')
-    env = dict(os.environ, VM_GEMM_TILE=tile, VM_TEST_CHILD='1')
+    env = dict(os.environ, VM_TEST_GEMM_TILE=tile, VM_TEST_CHILD='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-m', 'gpu', '-q', '-x', '-k', 'gemm_bf16 and not forced'],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -310,7 +311,7 @@ def test_forked_norms_and_linear_sum_the_residual_gradient(dev, K, dt):
 
 
 def test_vit_layer_with_the_linear_fork_matches_the_default(dev, K, monkeypatch):
-    """VM_FORK_LINEAR (off by default): a post-norm ViT-E layer whose residual gradients ride in the dgrad GEMM epilogues gives the
+    """functional.FORK_LINEAR (off by default): a post-norm ViT-E layer whose residual gradients ride in the dgrad GEMM epilogues gives the
     same output and, up to one bf16 rounding per sum, the same gradients as the default (autograd's own adds)"""
     from argparse import Namespace
     from mmmm_amd import functional as Fh

@@ -433,7 +433,7 @@ def test_side_stream_factor_gradients_match_main_stream(dev, lm):
 
 def test_lm_head_on_labelled_rows_equals_the_full_product(dev):
     """_LMHeadCE compacts the rows that carry a label (device-side, no sync) and runs lm_head + CE on those only. Against the full-size
-    form (VM_LMHEAD_LABEL_ROWS=0): loss, per-row CE and the hidden-state gradient bit-identical (a row's products do not depend on
+    form (modeling_cogvlm.LM_HEAD_LABEL_ROWS = False): loss, per-row CE and the hidden-state gradient bit-identical (a row's products do not depend on
     the other rows), the weight gradient equal up to the order of its fp32 row sum."""
     from mmmm_amd.models.cogvlm import modeling_cogvlm as mc
     g = torch.Generator(device='cpu').manual_seed(11)

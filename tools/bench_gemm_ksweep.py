@@ -8,7 +8,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from mmmm_amd import kernels as K
 dev = torch.device('cuda:0')
-tag = f"tile={os.environ.get('VM_GEMM_TILE','auto')} dbg={os.environ.get('VM_GEMM_DEBUG','0')}"
+_tile = int(os.environ.get('GEMM_TILE', '0'))          # tool-side knob: GEMM_TILE=128|192|256|-192 -> vm_gemm_force_tile_
+if _tile:
+    from mmmm_amd import hip as _hip
+    assert _hip.lib().vm_gemm_force_tile_(_tile) == 0
+tag = f"tile={_tile or 'auto'} dbg={os.environ.get('VM_GEMM_DEBUG','0')}"
 for M, N in ((6280, 15360), (6280, 1792), (3648, 4096)):
     pts = []
     for Kd in (256, 512, 1024, 1792, 4096, 8192):

@@ -1,4 +1,4 @@
-"""A/B timing of the ViT-shaped GEMMs (short K, wide N): VM_GEMM_TILE / VM_GEMM_DEBUG are read once per process."""
+"""A/B timing of the ViT-shaped GEMMs (short K, wide N): GEMM_TILE (this script -> vm_gemm_force_tile_) / VM_GEMM_DEBUG (debug builds of the library) are read once per process."""
 import sys, os
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -6,7 +6,11 @@ import torch
 from mmmm_amd import kernels as K
 from tools.bench_kernels import timeit
 dev = torch.device('cuda:0')
-tag = f"tile={os.environ.get('VM_GEMM_TILE','auto')} dbg={os.environ.get('VM_GEMM_DEBUG','0')}"
+_tile = int(os.environ.get('GEMM_TILE', '0'))          # tool-side knob: GEMM_TILE=128|192|256|-192 -> vm_gemm_force_tile_
+if _tile:
+    from mmmm_amd import hip as _hip
+    assert _hip.lib().vm_gemm_force_tile_(_tile) == 0
+tag = f"tile={_tile or 'auto'} dbg={os.environ.get('VM_GEMM_DEBUG','0')}"
 shapes = [(6280, 15360, 1792, 64, True), (6280, 15360, 1792, 64, False), (6280, 15360, 1792, 0, False), (6280, 1792, 15360, 64, True),
           (6280, 5376, 1792, 64, True), (6280, 1792, 1792, 64, True), (3648, 11008, 4096, 64, False), (3648, 4096, 11008, 64, False)]
 for M, N, Kd, K2, has_bias in shapes:

@@ -10,7 +10,7 @@ from mmmm_amd.models.lora import ActivationBudget, StepState
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
 import os
-w = bench.WORKLOADS[os.environ.get('VM_WORKLOAD', 'phase-vg-448')]
+w = bench.WORKLOADS[os.environ.get('WORKLOAD', 'phase-vg-448')]      # tool-side knob
 model, tok = bench.build(w, dev, float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 names = {id(p): n for n, p in model.named_parameters()}
 trainable = [p for p in model.parameters() if p.requires_grad]
