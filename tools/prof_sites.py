@@ -33,9 +33,18 @@ class Sites(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.count = collections.Counter()
+        self.views = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace('aten.', '')
+        # slices / selects of tensors that require grad: each becomes a zeros + copy (+ add) in the backward (SliceBackward0 / SelectBackward0)
+        if name.startswith(('slice', 'select', 'narrow', 'index.Tensor', 'unbind', 'split')) and args and isinstance(args[0], torch.Tensor) and args[0].requires_grad:
+            site = '?'
+            for fr in reversed(traceback.extract_stack(limit=24)):
+                if 'mmmm_amd/' in fr.filename and not fr.filename.endswith(('kernels.py', 'hip.py')):
+                    site = f"{fr.filename.split('mmmm_amd/')[-1]}:{fr.lineno} {fr.name}"
+                    break
+            self.views[(site, name)] += 1
         if not any(name.startswith(v) for v in VIEWS):
             site = '?'
             for fr in reversed(traceback.extract_stack(limit=24)):
@@ -69,6 +78,10 @@ for (site, name), c in sites.count.items():
 for site, c in by_site.most_common(60):
     ops = ', '.join(f'{n} x{k}' for (s, n), k in sorted(sites.count.items(), key=lambda kv: -kv[1]) if s == site)
     print(f'{c:6d}  {site}   [{ops[:150]}]')
+
+print('== forward: slices / selects of tensors that require grad (their backward is zeros + copy per use)')
+for (site, name), c in sites.views.most_common(40):
+    print(f'{c:6d}  {site}   [{name}]')
 
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step()
