@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
   const unsigned thr = vm_drop_threshold(p.drop_p);
   const float inv_keep = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int64_t m = row0 + wave * 16 + frow;
+  // mask index of the lane's 8 elements = m K + kk; below 2^34 elements the hash takes the 32-bit group index m (K / 4) + kk / 4
+  const bool idx32 = vm_fits32(p.M, p.K) && (p.K & 3) == 0;
+  const VmSeed sd = vm_seed(p.seed);
+  const unsigned g_row = (unsigned)m * (unsigned)(p.K >> 2);
 
   auto stage = [&](int kt, int buf) {        // K-tiles past the range stage zero rows: every wave issues 8 DMA instructions per call
     char* sx = smem + buf * DN_STAGE;
@@ -135,9 +139,14 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void lora_down_k(const Do
       u16x8_t xv = *reinterpret_cast<const u16x8_t*>(sx + tile_off(wave * 16 + frow, 4 * s + fq));
       if (drop) {
         const int kk = kt * 128 + 32 * s + 8 * fq;
-        const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
-        const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
-        vm_mask8(xv, h0, h1, thr);           // 1/(1-p) is applied to the accumulators below
+        if (idx32) {
+          const unsigned g = g_row + (unsigned)(kk >> 2);
+          vm_mask8w(xv, vm_hash4w(sd, g), vm_hash4w(sd, g + 1), thr);           // 1/(1-p) is applied to the accumulators below
+        } else {
+          const uint64_t idx = (uint64_t)m * (uint64_t)p.K + (uint64_t)kk;       // multiple of 8
+          const uint64_t h0 = vm_hash4(p.seed, idx >> 2), h1 = vm_hash4(p.seed, (idx >> 2) + 1);
+          vm_mask8(xv, h0, h1, thr);
+        }
       }
       const bf16x8_t xb = __builtin_bit_cast(bf16x8_t, xv);
 #pragma unroll
@@ -739,6 +748,8 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
   };
   const bool drop = q.drop_p > 0.f;
   const unsigned thr = vm_drop_threshold(q.drop_p);
+  const bool idx32 = vm_fits32(q.M, C) && (C & 3) == 0;
+  const VmSeed sd = vm_seed(q.seed);
   const TrLane trl = tr_lane(smem, lane);
 #pragma unroll
   for (int i = 0; i < GR_STAGES - 1; ++i) stage(i, i);
@@ -758,9 +769,14 @@ __global__ __launch_bounds__(256, GR_STAGES == 2 ? 3 : 2) void tn_group_k(const 
         const int col = c0 + ch * 8;
         char* addr = sw + (ch >> 4) * 32 * ROWB + tile_off(row, ch & 15);
         u16x8_t v = *reinterpret_cast<u16x8_t*>(addr);
-        const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)C + (uint64_t)col;
-        const uint64_t h0 = vm_hash4(q.seed, e >> 2), h1 = vm_hash4(q.seed, (e >> 2) + 1);
-        vm_mask8(v, h0, h1, thr);            // 1/(1-p) is folded into alpha by the launcher
+        if (idx32) {
+          const unsigned g = (unsigned)(r0 + row) * (unsigned)(C >> 2) + (unsigned)(col >> 2);
+          vm_mask8w(v, vm_hash4w(sd, g), vm_hash4w(sd, g + 1), thr);            // 1/(1-p) is folded into alpha by the launcher
+        } else {
+          const uint64_t e = (uint64_t)(r0 + row) * (uint64_t)C + (uint64_t)col;
+          const uint64_t h0 = vm_hash4(q.seed, e >> 2), h1 = vm_hash4(q.seed, (e >> 2) + 1);
+          vm_mask8(v, h0, h1, thr);
+        }
         *reinterpret_cast<u16x8_t*>(addr) = v;
       }
       // (not __syncthreads(): its fence would drain the DMA of the next step that was issued above)
