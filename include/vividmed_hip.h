@@ -335,7 +335,7 @@ int vm_tn_skinny_bf16(const void* W, int64_t ldw, int C, const void* S, int64_t 
  * counts_dev the routed segment `segment` (0: [0, counts[0]), 1: [counts[0], counts[1]), other: [0, counts[1])).
  * One workgroup per 64 columns of one item walks all of the item's rows: no partial sums, no atomics — deterministic.
  * `block0` is filled in by the call. C % 8 == 0, ldw % 8 == 0, lds % 8 == 0. */
-#define VM_TN_GROUP_MAX 24
+#define VM_TN_GROUP_MAX 32
 typedef struct {
   const void* W; int64_t ldw; int32_t C; int32_t M;
   const void* S; int64_t lds;

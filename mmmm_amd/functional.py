@@ -177,6 +177,8 @@ def abort_backward_state():
     for ring in _WGRAD_EVENTS.values():
         ring.clear()
     _WGRAD_QUEUE.clear()
+    _WGRAD_QUEUE_IDS.clear()
+    _WGRAD_QUEUE_WGS[0] = 0
     _WGRAD_QUEUE_STATE[0] = _WGRAD_QUEUE_STATE[1] = None
     if '_U_STASH' in globals():
         _U_STASH.clear()
@@ -248,6 +250,8 @@ def _off_critical_path(fn, device, keep_alive):
 WGRAD_GROUP = True
 _WGRAD_QUEUE: list = []           # [(item for kernels.tn_skinny_group, param, ready callback)]
 _WGRAD_QUEUE_IDS: set = set()     # id() of the queued parameters (the queued entries keep them alive)
+_WGRAD_QUEUE_WGS = [0]            # workgroups the queued items will launch
+WGRAD_GROUP_SLOTS = 768           # 3 workgroups of tn_group_k per CU x 256 CUs
 _WGRAD_QUEUE_STATE = [None, None]     # graph-task id of the backward pass the queue belongs to, stream its operands were produced on
 
 
@@ -264,6 +268,13 @@ def _queue_wgrad(param, ready, W, S, transpose_out, counts, seg, alpha, drop_p, 
         # the same slot twice in one grouped launch (a LoRA linear applied twice within 24 queued factors: shared modules, depth-1 models):
         # two workgroups would read-modify-write one tile unsynchronised — the earlier items go out first
         flush_wgrad_queue()
+    # A grouped launch is ONE round of workgroups (256 columns of one factor each, every one walking all rows at its own pace; three fit a
+    # CU): it should fill the 3 x CUs slots and never exceed them. ViT-E: 176 workgroups per layer -> four layers per launch (704 of 768;
+    # three layers = 528 ran at 4.0 TB/s where the path gives 5.3-5.5); decoder: 546 per layer -> a layer and a third.
+    wgs = (W.shape[1] + 255) // 256
+    if _WGRAD_QUEUE and _WGRAD_QUEUE_WGS[0] + wgs > WGRAD_GROUP_SLOTS:
+        flush_wgrad_queue()
+    _WGRAD_QUEUE_WGS[0] += wgs
     _WGRAD_QUEUE_IDS.add(id(param))
     _WGRAD_QUEUE.append(((W, S, param.grad, transpose_out, counts, seg, alpha, drop_p, seed), param, ready))
     if len(_WGRAD_QUEUE) >= hip.TN_GROUP_MAX:
@@ -278,6 +289,7 @@ def flush_wgrad_queue():
     items = _WGRAD_QUEUE[:]
     _WGRAD_QUEUE.clear()
     _WGRAD_QUEUE_IDS.clear()
+    _WGRAD_QUEUE_WGS[0] = 0
     st = _WGRAD_QUEUE_STATE[1]
     cur = hip.current_stream_obj(st.device)
     if cur is not st:

@@ -85,7 +85,7 @@ class AttnF32Args(C.Structure):
     ]
 
 
-TN_GROUP_MAX = 24
+TN_GROUP_MAX = 32
 
 
 class TnGroupItem(C.Structure):

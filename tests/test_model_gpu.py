@@ -169,9 +169,13 @@ def test_lm_backward_matches_oracle_with_lora_dropout_on(dev, lm):
     lm.train()
     lm.gradient_checkpointing_enable()
     batch, _ = make_inputs(dev, seed=11)
-    old_seed = StepState.seed
-    passes: dict = {}          # (lora_dropout_on numbers the sites itself: the masks do not depend on what the process built before)
+    old_seed, old_step = StepState.seed, StepState.step
+    # (lora_dropout_on numbers the sites itself and the step counter is pinned here: the three realisations do not depend on what the process
+    # built or stepped before — with the counter left at whatever earlier tests had bumped it to, a `-k` selection of the suite drew other masks
+    # than the full run and landed on a badly conditioned one)
+    passes: dict = {}
     try:
+        StepState.step = 0
         for seed in (1, 2, 3):
             StepState.seed = seed
             with lora_dropout_on(lm, batch['vlm_inputs'], 0.05) as masks:
@@ -221,7 +225,7 @@ def test_lm_backward_matches_oracle_with_lora_dropout_on(dev, lm):
         bad = {n: v for n, v in passes.items() if sum(ok for ok, _ in v) < 2}
         assert not bad, sorted(bad.items())[:10]
     finally:
-        StepState.seed = old_seed
+        StepState.seed, StepState.step = old_seed, old_step
         lm.model.gradient_checkpointing = False
         lm.model.vision.transformer.gradient_checkpointing = False
 
