@@ -922,14 +922,44 @@ static int& lora_two_kernels() { static int v = 0; return v; }
  * 1 = always two kernels (the form before round 5), 2 = one launch whenever legal */
 int vm_lora_down_two_kernels_(int mode) { lora_two_kernels() = (mode >= 0 && mode <= 2) ? mode : 0; return VM_OK; }
 
+static int& lora_down_target() { static int t = 512; return t; }
+/* internal (A/B): workgroup slots a lora_down launch may fill (two 64 KiB workgroups per CU x 256 CUs) */
+int vm_lora_down_target_(int wgs) { if (wgs == 0 || wgs < -4096 || wgs > 4096) return VM_ERR_BAD_ARG; lora_down_target() = wgs; return VM_OK; }      // < 0: the rule before round 5b (split until ~|wgs| workgroups), for A/B runs
+// K is always split (a single-pass form for short K measured 0.9 ms per step slower). Cost model of a launch (us): the chip holds `slots`
+// workgroups at once (two 64 KiB workgroups per CU); a workgroup walks `per` K-tiles of 128, one memory round trip in flight behind the one it
+// computes on: a ROUND of n workgroups takes max(latency-bound per x 1.25 us, bandwidth-bound n x per x 16 KiB / 5.5 TB/s) + 4 us of
+// dispatch / cold first tile / partial store (calibrated on [6280 x 1792 / 5376 / 15360]: 12.5 / 25 / 35 us at 4 splits), and a last round
+// of a few workgroups still costs a whole latency-bound workgroup. The split count with the
+// cheapest sum wins, with a small charge per split for the partials the reduce kernel reads. What this replaces — "split until ~384
+// workgroups" — put 514 workgroups on 512 slots at 16 392 rows (two stragglers doubling the launch) and 534 at 11 336; at 6 280 rows it
+// gave 4 splits (396) where 5 (495 of 512) is one K-tile shorter per workgroup: 300.2 / 301.0 -> 299.9 / 299.2 ms per step, A B A B.
 static int lora_down_ksplits(int M, int K, bool segmented) {
   const int m_tiles = (M + DN_BM - 1) / DN_BM + (segmented ? 1 : 0);
   const int kt = (K + 127) / 128;
-  constexpr int target = 384;          // ~1.5 workgroups per CU (always split: a single-pass form for short K measured 0.9 ms per step slower)
-  int want = (target + m_tiles - 1) / m_tiles;
-  want = max(1, min(want, kt / 2));
-  const int per = (kt + want - 1) / want;
-  return (kt + per - 1) / per;
+  // few row blocks (decode steps, small models): the launch is one partial round whatever the split — keep the rule those paths were tuned
+  // and pinned with (split until ~384 workgroups, at least two K-tiles each)
+  if (lora_down_target() < 0 || m_tiles < 32) {
+    int want = ((lora_down_target() < 0 ? -lora_down_target() : 384) + m_tiles - 1) / m_tiles;
+    want = max(1, min(want, kt / 2));
+    const int per = (kt + want - 1) / want;
+    return (kt + per - 1) / per;
+  }
+  const int slots = lora_down_target();
+  int best = 1;
+  double best_cost = 1e30;
+  for (int want = 1; want <= max(1, kt / 2) && want <= 64; ++want) {
+    const int per = (kt + want - 1) / want;
+    const int s = (kt + per - 1) / per;
+    if (s != want) continue;                                   // (only split counts that are actually reached)
+    const int64_t wgs = (int64_t)m_tiles * s;
+    const int64_t full = wgs / slots, rest = wgs % slots;
+    const double t_lat = 1.25 * per, t_bw_full = (double)slots * per * 0.00298;
+    double cost = (double)full * ((t_lat > t_bw_full ? t_lat : t_bw_full) + 4.0);
+    if (rest) { const double t_bw = (double)rest * per * 0.00298; cost += (t_lat > t_bw ? t_lat : t_bw) + 4.0; }
+    cost += 0.15 * s;
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 int vm_lora_down_workspace(int M, int K, int segmented, int64_t* bytes_host) {

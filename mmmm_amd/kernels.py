@@ -278,9 +278,17 @@ def colsum(x: torch.Tensor, nrows: torch.Tensor | None = None, out: torch.Tensor
     return out
 
 
+LORA_DOWN_TARGET_WGS = 512          # workgroup slots a lora_down launch may fill (vm_lora_down_target_); A/B: bench.py --set kernels.LORA_DOWN_TARGET_WGS=...
+_lora_down_target_applied = [512]
+
+
 def lora_down(x: torch.Tensor, A0: torch.Tensor, A1: torch.Tensor | None = None, *, counts: torch.Tensor | None = None,
               split: int = -1, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """t[M,64] = drop(x) @ A^T (bf16; rank 64; K % 8 == 0)"""
+    if LORA_DOWN_TARGET_WGS != _lora_down_target_applied[0]:
+        hip.call('vm_lora_down_target_', int(LORA_DOWN_TARGET_WGS))
+        _lora_down_target_applied[0] = LORA_DOWN_TARGET_WGS
+        _lora_ws_bytes.cache_clear()
     M, Kd = x.shape
     t = torch.empty(M, A0.shape[0], dtype=x.dtype, device=x.device)
     segmented = counts is not None or split >= 0
