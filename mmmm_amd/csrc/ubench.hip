@@ -48,25 +48,25 @@ extern "C" int vm_ubench_mfma_bf16(float seconds, float* tflops_host, void* stre
   const int iters = 4000;                                            // ~4-5 ms per launch
   const double flops_per_launch = (double)cus * 8 /*waves*/ * iters * 8 /*accumulators*/ * 2.0 * 16 * 16 * 32;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(sink); return VM_ERR_LAUNCH; }
   // first half: load only (the clock settles); second half: timed
   double done_s = 0.0, timed_s = 0.0, timed_flops = 0.0;
   int rc = VM_OK;
   while (done_s < seconds) {
     const bool timed = done_s >= 0.5 * seconds;
     const int reps = 20;
-    hipEventRecord(e0, st);
+    (void)hipEventRecord(e0, st);
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(mfma_rate_k, dim3(cus), dim3(512), 0, st, sink, iters, 1234u + r);
-    hipEventRecord(e1, st);
+    (void)hipEventRecord(e1, st);
     if (hipEventSynchronize(e1) != hipSuccess) { rc = VM_ERR_LAUNCH; break; }
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = VM_ERR_LAUNCH; break; }
     done_s += ms * 1e-3;
     if (timed) { timed_s += ms * 1e-3; timed_flops += flops_per_launch * reps; }
     if (ms <= 0.f) { rc = VM_ERR_LAUNCH; break; }
   }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  hipFree(sink);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
   if (rc != VM_OK) return rc;
   *tflops_host = timed_s > 0 ? (float)(timed_flops / timed_s / 1e12) : 0.f;
   return VM_OK;
