@@ -44,7 +44,7 @@ extern "C" {
 #define VM_ACT_RELU 2
 
 /* library / device info --------------------------------------------------- */
-int vm_version(void);   /* 500 = round 5 (vm_gemm_args grew by workspace / workspace_bytes; vm_gemm_workspace_bytes added; vm_lora_down_fused removed), 400 = round 4
+int vm_version(void);   /* 510 = VM_TN_GROUP_MAX 24 -> 32; 500 = round 5 (vm_gemm_args grew by workspace / workspace_bytes; vm_gemm_workspace_bytes added; vm_lora_down_fused removed), 400 = round 4
                           * (vm_attn_args grew by workspace / workspace_bytes). The argument structs below only ever GROW at their end; a caller built against an older
                           * header must be rebuilt when this number changes (there is no struct_size field). */
 /* fills name[0..len) with the gcnArchName of the current device */

@@ -70,14 +70,19 @@ __device__ __forceinline__ void split_f32x8(const f32x4_t& lo4, const f32x4_t& h
 //   of the co-resident waves.
 // BMT = 128: 4 waves 2x2, wave tile 64 x 64.  BMT = 64 (fp32 output only): 4 waves 1x4, wave tile 64 rows x 32 columns —
 // twice the workgroups for the M ~ 3k fp32 linears of SAM / iSAM, whose 128-row grids (150 tiles) leave 40 % of the CUs idle.
-template <int ESZ, bool OUT_F32, int BMT = 128, int NS = 0>
+// BNT = output columns per tile: 128, or 32 for the TAILS launch of the two-launch plan (sched_plan kind 3) — a few dozen rows against all N
+// columns: with 128-column tiles 64 workgroups each streamed 1 MB of weights through ONE CU's DMA path (~25 GB/s: 44 us at K = 4160, 110 us at
+// 11 072); 32-column tiles put the same bytes on every CU.
+template <int ESZ, bool OUT_F32, int BMT = 128, int NS = 0, int BNT = BN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   static_assert(BMT == 128 || (BMT == 64 && OUT_F32), "the 64-row tile has the direct fp32 epilogue only");
   static_assert(NS == 0 || ESZ == 4, "the split applies to fp32 operands");
+  static_assert(BNT == BN || (BNT == 32 && BMT == 128 && ESZ == 2 && !OUT_F32), "the 32-column tile exists for the bf16 tails launch");
+  constexpr int B_TILE = BNT * 128;                      // weight tile bytes
   constexpr int BKE = 128 / ESZ;  // K elements per tile
-  constexpr int NI = BMT == 128 ? 4 : 2;                 // 16-wide n sub-tiles per wave
+  constexpr int NI = BMT == 128 ? BNT / 32 : 2;          // 16-wide n sub-tiles per wave
   constexpr int A_TILE = BMT * 128;                      // activation tile bytes
-  constexpr int STAGE = A_TILE + TILE_BYTES;
+  constexpr int STAGE = A_TILE + B_TILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   int row0, nrows, seg;
   gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
   if (nrows <= 0) return;
-  const int n0 = tn * BN;
-  const int ncols = min(BN, p.N - n0);
+  const int n0 = tn * BNT;
+  const int ncols = min(BNT, p.N - n0);
 
   const char* Bw = seg ? p.B1 : p.B0;
   const char* B2w = seg ? p.B2_1 : p.B2_0;
@@ -148,11 +153,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
       char* sb = sa + A_TILE;
       if (EXT_NEXT) {
         stage_tile<BMT>(rA2, lda2_b, (t + 1) * 128, sa, wave, lane);
-        stage_tile(rB2, ldb2_b, (t + 1) * 128, sb, wave, lane);
+        stage_tile<BNT>(rB2, ldb2_b, (t + 1) * 128, sb, wave, lane);
       } else {
         const int koff = (t + 1 - kt_ext) * 128;
         stage_tile<BMT>(rA, lda_b, koff, sa, wave, lane);
-        stage_tile(rB, ldb_b, koff, sb, wave, lane);
+        stage_tile<BNT>(rB, ldb_b, koff, sb, wave, lane);
       }
     }
     const char* sa = smem + buf * STAGE + wm * (64 * 128);
@@ -234,10 +239,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
 
   if (kt_ext > 0) {
     stage_tile<BMT>(rA2, lda2_b, 0, smem, wave, lane);
-    stage_tile(rB2, ldb2_b, 0, smem + A_TILE, wave, lane);
+    stage_tile<BNT>(rB2, ldb2_b, 0, smem + A_TILE, wave, lane);
   } else {
     stage_tile<BMT>(rA, lda_b, 0, smem, wave, lane);
-    stage_tile(rB, ldb_b, 0, smem + A_TILE, wave, lane);
+    stage_tile<BNT>(rB, ldb_b, 0, smem + A_TILE, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // tile 0 landed
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
     }
   } else {
     // all waves are past the last K-step barrier: the staging LDS is free. 64 x 64 slab per wave.
-    typedef EpiSlab<64, 64> Slab;
+    typedef EpiSlab<64, NI * 16> Slab;
     char* slab = smem + wave * Slab::BYTES;
     const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
-    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * (NI * 16) >= 64 && ((uintptr_t)bias & 7) == 0;
+    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * (NI * 16) >= NI * 16 && ((uintptr_t)bias & 7) == 0;
     if (fast_bias) {
-      f32x4_t bv[4];
+      f32x4_t bv[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) bv[i] = epi_bias4(bias, n0 + wn * (NI * 16) + i * 16 + fq * 4);
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
         else epi_put4<1>(slab, Slab::PITCH, j * 16 + frow, i * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, acc[i][j]);
       }
     // same-wave LDS round trip: the compiler orders the ds_reads behind the ds_writes (lgkmcnt)
-    epi_flush<64, 64>(slab, p, row0 + wm * 64, n0 + wn * (NI * 16), nrows - wm * 64, ncols - wn * (NI * 16), lane);
+    epi_flush<64, NI * 16>(slab, p, row0 + wm * 64, n0 + wn * (NI * 16), nrows - wm * 64, ncols - wn * (NI * 16), lane);
   }
 }
 
@@ -493,7 +498,7 @@ extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, do
 
 extern "C" {
 
-int vm_version(void) { return 500; }      /* 500: round 5 (vm_gemm_args.workspace / workspace_bytes, vm_gemm_workspace_bytes); 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
+int vm_version(void) { return 510; }      /* 510: VM_TN_GROUP_MAX 24 -> 32 (vm_tn_skinny_group_bf16 takes up to 32 items); 500: round 5 (vm_gemm_args.workspace / workspace_bytes, vm_gemm_workspace_bytes); 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
 
 int vm_device_arch(char* name_host, int len) {
   int dev = 0;
@@ -552,7 +557,7 @@ extern "C" int64_t vm_gemm256sk_workspace_(int workers);
 // Model (us, measured on MI355X with tools/ubench/gemm_bench: DESIGN.md section 3): a K-tile of the 256-row body takes T_K per CU, of the
 // 192-row body 0.78 T_K; every segment a workgroup runs pays a fixed C_SEG (descriptors + first K-tile's latency + output stores); a
 // split tile adds C_FIX (slab out, slab in, flag). The 128-tile kernel (two workgroups per CU) is for shapes with a handful of tiles.
-struct SkPlan { int kind; int rows; };     // kind 0: 128-tile kernel, 1: DP, 2: stream-K
+struct SkPlan { int kind; int rows; };     // kind 0: 128-tile kernel, 1: DP, 2: stream-K, 3: FULL 256-row tiles + a tails launch of 128 x 128 tiles
 static int cu_count() {
   static int n = [] { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
                       return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }();
@@ -563,6 +568,10 @@ static int cu_count() {
 // step, every XCD's L2 then fetches each panel once per WORKGROUP instead of once), 1 by the cost model below, 2 whenever legal (tests,
 // tools/ubench/gemm_bench): vm_gemm_sched_mode_
 static int& sk_mode() { static int mode = 0; return mode; }
+// 1 (default): the scheduler may split a launch into full 256-row tiles + a tails launch (plan kind 3); vm_gemm_tails_mode_(0) turns it off (A/B, tests)
+static int& tails_mode() { static int mode = 1; return mode; }
+static bool tails_ok() { return tails_mode() != 0; }
+extern "C" int vm_gemm_tails_mode_(int mode) { if (mode < 0 || mode > 4) return VM_ERR_BAD_ARG; tails_mode() = mode; return VM_OK; }      // 2: whenever legal (tests)
 extern "C" int vm_gemm_sched_mode_(int mode) { if (mode < 0 || mode > 2) return VM_ERR_BAD_ARG; sk_mode() = mode; return VM_OK; }
 static unsigned sk_next_epoch() { static std::atomic<unsigned> e{0}; unsigned v; do { v = ++e; } while (v == 0); return v; }
 
@@ -576,7 +585,7 @@ extern "C" int vm_gemm_force_tile_(int tile) {
   forced_tile() = tile;
   return VM_OK;
 }
-static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool sk_ok) {
+static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool sk_ok, bool tails = true) {
   const int forced = forced_tile();
   if (forced == 128) return {0, 0};
   if (forced == 256 || forced == 192) return {1, forced};
@@ -598,6 +607,18 @@ static SkPlan sched_plan(int M, int N, int kt, double tk, bool segmented, bool s
     if (sk_mode() == 2) csk = 0.0;
   }
   const double cdp = c192 < c256 ? c192 : c256;
+  // FULL + TAILS (two launches): the 256-row kernel runs only the tiles that are full — a partial tile's workgroup leaves at once — and the
+  // rows behind each segment's last full tile (< 256 per segment) go to the 128 x 128 kernel in a second, short launch. It pays where the
+  // partial tiles are what opens a new round: the decoder's N = 4096 linears at 4128 / 4176 rows are 16 full tiles x 16 + 32 nearly empty ones
+  // (two segments of 2064 rows = 8 x 256 + 16) — 288 tiles = two rounds of 192-row tiles at 1.56 tile-times, against ONE round of 256 full tiles
+  // + ~0.2 for the tails. The host only knows M (the segment boundary is a device count): floor(M / 256) x tn bounds the full tiles from above.
+  double cft = 1e30;
+  if (tails && tails_ok() && forced == 0) {
+    const int64_t tfull = (int64_t)(M / 256) * tn;
+    if (tfull > 0) cft = (double)((tfull + W - 1) / W) * (work + SK_C_SEG) + (0.5 * kt + 8.0);        // tails: a 128 x 32 workgroup walks K at ~0.5 us per K-tile (measured: 37 us at K = 4160, 87 at 11 072, 27 at 1 856)
+  }
+  if (tails_mode() >= 2 && cft < 1e29) return {3, 256};
+  if (cft < cdp && cft < c128 && cft < csk) return {3, 256};
   if (csk < cdp && csk < c128) return {2, 256};
   if (c128 < cdp) return {0, 0};
   return {1, c192 < c256 ? 192 : 256};
@@ -652,6 +673,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   p.ksplit = 1; p.kchunk = a->K;
   p.row_scale = nullptr; p.col_scale0 = p.col_scale1 = nullptr;
   p.b_nn = 0;
+  p.row_filter = 0; p.tail_base = 256; p.tiles_m_override = 0;
   if (a->ksplit > 1) {
     if (a->out_dtype != VM_F32 || a->act != VM_ACT_NONE || a->K2 != 0) return VM_ERR_BAD_ARG;
     const int kt = a->K / bke;
@@ -685,6 +707,7 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   vm_prof_begin_(kind, stream, &tok);
   const bool sk_ok = esz == 2 && !a->b_nn && a->workspace && a->workspace_bytes >= vm_gemm256sk_workspace_(cu_count());
   SkPlan plan = (esz == 2 && p.ksplit <= 1) ? sched_plan(a->M, a->N, (a->K + a->K2) / 64, SK_T_K_BF16, segmented, sk_ok) : SkPlan{0, 0};
+  if (plan.kind == 3 && (a->b_nn || a->out_dtype != VM_BF16)) plan = SkPlan{1, 192};      // (the tails launch is the bf16 128 x 128 kernel)
   int big = plan.kind ? plan.rows : 0;
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
@@ -694,6 +717,17 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   if (big && plan.kind == 2 && !a->b_nn) {
     const int rc = vm_gemm256sk_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, 0, cu_count(), a->workspace, sk_next_epoch(), stream);
     if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
+  } else if (big && plan.kind == 3) {
+    GemmParams pf = p;
+    pf.row_filter = 1;                                          // launch 1: the full 256-row tiles, indexed compactly (tiles_m = an upper bound of their rows)
+    pf.tiles_m_override = a->M / 256;
+    const int rc = tails_mode() == 4 ? VM_OK : vm_gemm256_launch_(&pf, 0, segmented ? 1 : 0, 256, 0, stream);      // (modes 3 / 4: timing experiments — only the first / only the second launch)
+    if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
+    GemmParams pt = p;
+    pt.row_filter = 2; pt.tail_base = 256;                      // launch 2: < 256 rows per segment in 128-row tiles (two per segment)
+    pt.tiles_m = segmented ? 4 : 2;
+    pt.tiles_n = (a->N + 31) / 32;                              // 32-column tiles: every CU streams a slice of the weights
+    if (tails_mode() != 3) hipLaunchKernelGGL((gemm_nt_k<2, false, 128, 0, 32>), dim3(pt.tiles_m * pt.tiles_n), dim3(256), 2 * (128 * 128 + 32 * 128), (hipStream_t)stream, pt);
   } else if (big) {
     const int rc = vm_gemm256_launch_(&p, a->out_dtype == VM_F32, segmented ? 1 : 0, big, a->b_nn ? 2 : 0, stream);
     if (rc != VM_OK) { vm_prof_end2_(kind, stream, tok, 0.0, 0.0); return rc; }
@@ -780,10 +814,11 @@ int vm_gemm_fp8(const vm_gemm_args* a, const float* row_scale, const float* col_
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed;
   p.ksplit = 1; p.kchunk = a->K;
   p.b_nn = 0;
+  p.row_filter = 0; p.tail_base = 256; p.tiles_m_override = 0;
   p.row_scale = row_scale; p.col_scale0 = col_scale; p.col_scale1 = col_scale_1 ? col_scale_1 : col_scale;
   p.dbg = gemm_dbg();
   const bool sk_ok = a->workspace && a->workspace_bytes >= vm_gemm256sk_workspace_(cu_count());
-  SkPlan plan = sched_plan(a->M, a->N, a->K / 128 + a->K2 / 64, SK_T_K_F8, segmented, sk_ok);
+  SkPlan plan = sched_plan(a->M, a->N, a->K / 128 + a->K2 / 64, SK_T_K_F8, segmented, sk_ok, false);      // (no fp8 128 x 128 kernel for a tails launch)
   if (!plan.kind) plan = SkPlan{1, 256};                                      /* the fp8 main loop exists in the 256-column kernel only */
   void* tok = nullptr;
   vm_prof_begin_(VM_PROF_GEMM_BF16, stream, &tok);

@@ -531,7 +531,7 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   // f8: 0 bf16 NT, 1 e4m3 NT, 2 bf16 with the weight in NN form (p.b_nn)
   GemmParams p = *(const GemmParams*)params;
   if (tile_rows != 256 && tile_rows != 192) return VM_ERR_BAD_ARG;
-  p.tiles_m = (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
+  p.tiles_m = p.tiles_m_override > 0 ? p.tiles_m_override : (p.M + tile_rows - 1) / tile_rows + (segmented ? 1 : 0);
   p.tiles_n = (p.N + 255) / 256;
   static std::once_flag attr_once;          // (called from the main thread and from autograd's backward thread)
   static bool attr_ok = false;

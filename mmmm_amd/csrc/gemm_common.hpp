@@ -40,6 +40,11 @@ struct GemmParams {
   // stream-K (gemm256sk_k): fp32 accumulator slabs [sk_workers][8 waves][2 MI x 4 registers][64 lanes][4], one flag word per worker
   // (= sk_epoch once the worker's slab is complete; epochs grow monotonically per process, so nothing is ever re-zeroed)
   float* sk_slabs; unsigned* sk_flags; unsigned sk_epoch; int sk_workers;
+  // row filter of the two-launch plan (gemm.hip: sched_plan kind 3): 0 every tile; 1 only the FULL tiles of each row segment (a partial
+  // tile's workgroup leaves at once); 2 only the rows behind the last full `tail_base`-row tile of each segment — tile index tm = 2 * segment +
+  // (0 | 1) of the 128-row kernel
+  int row_filter, tail_base;
+  int tiles_m_override;      // row_filter 1: tile rows of the grid (vm_gemm256_launch_ would size it for every tile)
   int dbg;   // timing-experiment builds only (-DVM_GEMM_DEBUG_BUILD): bit0 = zero-record descriptors (no operand traffic), bit1 = no XCD remap
 };
 
@@ -79,6 +84,27 @@ __device__ __forceinline__ void gemm_tile_rows(const GemmParams& p, int tm, int&
     M = min(p.M, __builtin_amdgcn_readfirstlane(p.counts_dev[1]));
   }
   seg = 0;
+  if (p.row_filter == 2) {
+    // the tails launch: tm = 2 * segment + k, k-th BM_-row tile behind the segment's last full tail_base-row tile
+    if (split >= 0) split = min(split, M);
+    seg = tm >> 1;
+    const int s_begin = (seg && split >= 0) ? split : 0, s_end = (split >= 0 && !seg) ? split : M;
+    if (seg && split < 0) { row0 = 0; nrows = 0; return; }
+    row0 = s_begin + ((s_end - s_begin) / p.tail_base) * p.tail_base + (tm & 1) * BM_;
+    nrows = min(BM_, s_end - row0);
+    return;
+  }
+  if (p.row_filter == 1) {
+    // the full-tiles launch: tm counts FULL tiles only (segment 0's, then segment 1's) — the grid holds no workgroup that would leave at once,
+    // so the XCD-contiguous chunks of the tile order stay equally loaded (with the partial tiles in the grid, an XCD whose chunk held none of
+    // them ran 36 tiles on 32 CUs: two rounds, 171 us where one round takes ~105)
+    if (split < 0) { row0 = tm * BM_; nrows = (row0 + BM_ <= M) ? BM_ : 0; return; }
+    split = min(split, M);
+    const int f0 = split / BM_;
+    if (tm < f0) { row0 = tm * BM_; nrows = BM_; }
+    else { seg = 1; row0 = split + (tm - f0) * BM_; nrows = (row0 + BM_ <= M) ? BM_ : 0; }
+    return;
+  }
   if (split < 0) {
     row0 = tm * BM_; nrows = min(BM_, M - row0);
   } else {

@@ -30,6 +30,8 @@ def _ld(t: torch.Tensor) -> int:
 
 # ------------------------------------------------------------------ GEMM
 _GEMM_WS: dict = {}
+GEMM_TAILS = True            # the scheduler may run a launch as full 256-row tiles + a tails launch (vm_gemm_tails_mode_); A/B: bench.py --set kernels.GEMM_TAILS=False
+_gemm_tails_applied = [True]
 
 
 def gemm_workspace() -> torch.Tensor:
@@ -67,6 +69,9 @@ def gemm(
     `workspace` (bf16): `gemm_workspace()` — lets the library run the stream-K form where its scheduler asks for it (off by default: measured
     slower on every shape of the six workloads; `tests/test_gemm_sched_gpu.py` forces it).
     """
+    if GEMM_TAILS != _gemm_tails_applied[0]:
+        hip.call('vm_gemm_tails_mode_', int(bool(GEMM_TAILS)))
+        _gemm_tails_applied[0] = GEMM_TAILS
     if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
         assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.dtype == torch.bfloat16 and out is None, (a.shape, w.shape)
         M, K = a.shape

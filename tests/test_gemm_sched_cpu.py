@@ -31,16 +31,18 @@ def test_no_chip_filling_shape_on_the_small_tile_kernel(plan):
         for N, K in ((4096, 4096), (4096, 11008), (11008, 4096), (12288, 4096), (4096, 12288)):
             kind, rows = plan(M, N, K, 64, 1)
             t256 = (-(-M // 256) + 1) * -(-N // 256)
-            assert t256 < 200 or (kind == 1 and rows in (192, 256)), (M, N, K, kind, rows)
+            assert t256 < 200 or (kind == 1 and rows in (192, 256)) or (kind, rows) == (3, 256), (M, N, K, kind, rows)
     for M in VIT:
         for N, K in ((5376, 1792), (1792, 1792), (15360, 1792), (1792, 15360), (1792, 5376)):
             kind, rows = plan(M, N, K, 64, 0)
-            assert kind == 1 and rows in (192, 256), (M, N, K, kind, rows)
+            assert (kind == 1 and rows in (192, 256)) or (kind, rows) == (3, 256), (M, N, K, kind, rows)      # (16 392 = 64 x 256 + 8 rows: full tiles + tails)
 
 
 def test_known_choices(plan):
     assert plan(3648, 4096, 4096, 64, 1) == (1, 256)          # 16 x 16 = 256 tiles: one round of 256-row tiles
-    assert plan(4128, 4096, 4096, 64, 1) == (1, 192)          # 288 tiles of 256 rows = 1.06 rounds -> 2 rounds of 192-row tiles
+    assert plan(4128, 4096, 4096, 64, 1) == (3, 256)          # 288 tiles of 256 rows, 32 of them nearly empty: ONE round of full tiles + a tails launch
+    assert plan(4176, 12288, 4096, 64, 1) == (3, 256)         # 16 x 48 = 768 full tiles = three rounds exactly, tails aside
+    assert plan(3648, 11008, 4096, 64, 1)[0] == 1             # 688 tiles: three rounds with or without the partial tiles -> one launch
     assert plan(6280, 1792, 15360, 64, 0) == (1, 192)         # 175 tiles of 256 rows leave 81 CUs idle; 231 of 192 rows
     assert plan(6280, 15360, 1792, 64, 0) == (1, 256)         # 1 500 tiles: 6 rounds either way, the 256-row body is the faster one
     assert plan(456, 4096, 4096, 64, 1)[0] in (0, 1)           # a single sample: too few tiles for the cost model to matter
@@ -50,11 +52,22 @@ def test_known_choices(plan):
 def test_stream_k_is_off_unless_forced(plan):
     from mmmm_amd import hip
     lib = hip.lib()
-    assert plan(4128, 4096, 4096, 64, 1, ws=1)[0] == 1
+    assert plan(4128, 4096, 4096, 64, 1, ws=1)[0] in (1, 3)
     lib.vm_gemm_sched_mode_(2)
     try:
         assert plan(4128, 4096, 4096, 64, 1, ws=1) == (2, 256)
-        assert plan(4128, 4096, 4096, 64, 1, ws=0)[0] == 1     # no workspace, no stream-K
+        assert plan(4128, 4096, 4096, 64, 1, ws=0)[0] in (1, 3)     # no workspace, no stream-K
         assert plan(3648, 12288, 4096, 64, 1, ws=1)[0] == 1    # 768 tiles: whole rounds, nothing to stream
     finally:
         lib.vm_gemm_sched_mode_(0)
+
+
+def test_full_plus_tails_can_be_switched_off(plan):
+    from mmmm_amd import hip
+    lib = hip.lib()
+    assert plan(4128, 4096, 4096, 64, 1) == (3, 256)
+    assert lib.vm_gemm_tails_mode_(0) == 0
+    try:
+        assert plan(4128, 4096, 4096, 64, 1) == (1, 192)      # the one-launch choice of the cost model
+    finally:
+        lib.vm_gemm_tails_mode_(1)

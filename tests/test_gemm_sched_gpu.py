@@ -127,4 +127,40 @@ def test_scheduler_never_puts_a_chip_filling_shape_on_the_small_tile_kernel(dev)
                 plan(M, N, Kd, 64, seg, 0, C.addressof(kind), C.addressof(rows))
                 t256 = (-(-M // 256) + seg) * -(-N // 256)
                 if t256 >= 200:          # more than 200 workgroups' worth of 256 x 256 tiles
-                    assert kind.value == 1 and rows.value in (192, 256), (M, N, Kd, seg, kind.value)
+                    assert (kind.value == 1 and rows.value in (192, 256)) or (kind.value, rows.value) == (3, 256), (M, N, Kd, seg, kind.value)
+
+
+# ---- plan kind 3: the FULL 256-row tiles in one launch, the rows behind each segment's last full tile in a second one (128 x 128 tiles)
+TAIL_SHAPES = [(4128, 4096, 2048, 64, 2064), (4176, 4096, 2048, 64, 4104), (4128, 12288, 1024, 64, 2064), (4128, 4096, 2048, 64, 2048), (4128, 4096, 2048, 0, 0),
+               (4128, 4096, 2048, 64, 4128), (4100, 4096, 2048, 64, 130), (4128, 4096, 128, 64, 2064), (4128, 4096, 128, 0, 2064)]
+
+
+@pytest.mark.parametrize('M,N,Kd,K2,split', TAIL_SHAPES)
+def test_full_plus_tails_launches_equal_the_single_launch_bit_for_bit(dev, K, M, N, Kd, K2, split):
+    """every row is computed exactly once — full tiles by the 256-row kernel (partial tiles' workgroups leave), the < 256 leftover rows of
+    each segment by the 128 x 128 kernel — with the same K order and the same instruction per product: identical bits. Segment boundaries
+    on a tile edge, an empty segment, a segment that is ALL tail, LoRA extension with the dgrad dropout mask, bias and residual included."""
+    from mmmm_amd import hip
+    lib = hip.lib()
+    a, w, w1, a2, b2, b21, bias, res = _operands(dev, M, N, Kd, K2, 7 * M + N + Kd)
+    counts = torch.tensor([split, M], dtype=torch.int32, device=dev)
+    kw = dict(w1=w1, a2=a2, b2=b2, b2_1=b21 if K2 else None, bias=bias, bias1=bias, residual=res, counts=counts,
+              drop_p=0.05 if K2 else 0.0, drop_seed=1234)
+    plan = lib.vm_gemm_plan_
+    plan.argtypes = [C.c_int] * 6 + [C.c_void_p] * 2
+    kind, rows = C.c_int(), C.c_int()
+    plan(M, N, Kd, K2, 1, 0, C.addressof(kind), C.addressof(rows))
+    assert lib.vm_gemm_tails_mode_(2) == 0          # 2: the two-launch plan wherever it is legal (the short-K shapes exercise the ring's start-up and drain)
+    try:
+        plan(M, N, Kd, K2, 1, 0, C.addressof(kind), C.addressof(rows))
+        assert kind.value == 3, 'the shape is meant to take the two-launch plan'
+        two = K.gemm(a, w, **kw)
+    finally:
+        lib.vm_gemm_tails_mode_(1)
+    assert lib.vm_gemm_tails_mode_(0) == 0
+    try:
+        one = K.gemm(a, w, **kw)
+    finally:
+        lib.vm_gemm_tails_mode_(1)
+    torch.cuda.synchronize()
+    assert torch.equal(two, one), (two.float() - one.float()).abs().max().item()
