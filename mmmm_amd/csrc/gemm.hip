@@ -27,14 +27,18 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // double buffer = 64 KiB
 
 // Issue the LDS-DMA loads of one 128x64 bf16 operand tile. `rsrc` covers the tile's valid rows
 // (rows past the end read as zero), `ld_bytes` is the row pitch, `koff` the byte offset of the K-tile.
+// `rows_valid`: 8-row pieces that lie entirely past it are NOT issued (their LDS rows keep whatever they held: the products of those rows
+// are never stored). A launch of a few rows — the tails launch of the two-launch plan, the mask decoder's token-count GEMMs — walks K one
+// tile at a time, and what a K-tile costs such a workgroup is mostly the issue of its DMA pieces (~60-130 cycles each, zero-fill or not).
 template <int ROWS = 128>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, int ld_bytes, int koff,
-                                           char* lds_tile, int wave, int lane) {
+                                           char* lds_tile, int wave, int lane, int rows_valid = 1 << 30) {
   constexpr int PW = ROWS / 32;   // wave-instructions (8 rows each) per wave
   const int r8 = lane >> 3, slot = lane & 7;
   const int chunk = slot ^ r8;  // source chunk that lands in LDS slot `slot` of row (.. + r8)
 #pragma unroll
   for (int i = 0; i < PW; ++i) {
+    if ((wave * PW + i) * 8 >= rows_valid) continue;          // (wave-uniform)
     const int row = (wave * PW + i) * 8 + r8;
     const int voff = row * ld_bytes + chunk * 16;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_tile + (wave * PW + i) * 1024), 16, voff, koff, 0, 0);
@@ -152,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
       char* sa = smem + (buf ^ 1) * STAGE;
       char* sb = sa + A_TILE;
       if (EXT_NEXT) {
-        stage_tile<BMT>(rA2, lda2_b, (t + 1) * 128, sa, wave, lane);
+        stage_tile<BMT>(rA2, lda2_b, (t + 1) * 128, sa, wave, lane, nrows);
         stage_tile<BNT>(rB2, ldb2_b, (t + 1) * 128, sb, wave, lane);
       } else {
         const int koff = (t + 1 - kt_ext) * 128;
-        stage_tile<BMT>(rA, lda_b, koff, sa, wave, lane);
+        stage_tile<BMT>(rA, lda_b, koff, sa, wave, lane, nrows);
         stage_tile<BNT>(rB, ldb_b, koff, sb, wave, lane);
       }
     }
@@ -238,10 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(const GemmParams p) {
   const std::false_type F_{};
 
   if (kt_ext > 0) {
-    stage_tile<BMT>(rA2, lda2_b, 0, smem, wave, lane);
+    stage_tile<BMT>(rA2, lda2_b, 0, smem, wave, lane, nrows);
     stage_tile<BNT>(rB2, ldb2_b, 0, smem + A_TILE, wave, lane);
   } else {
-    stage_tile<BMT>(rA, lda_b, 0, smem, wave, lane);
+    stage_tile<BMT>(rA, lda_b, 0, smem, wave, lane, nrows);
     stage_tile<BNT>(rB, ldb_b, 0, smem + A_TILE, wave, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
