@@ -613,11 +613,14 @@ def expert_index_build(token_type_ids: torch.Tensor, attention_mask: torch.Tenso
 
 
 # ------------------------------------------------------------------ attention (bf16, var-len)
-# The backward's dS^T scratch pays while the N x N matrix is cheap beside the recomputation it saves: measured 8 x 785 and 8 x 456 faster
-# (dQ 103 -> 47 us, 61 -> 31 us against +11 / +5 us on dK/dV), 8 x 2049 equal, 4 x 4609 slower — so the switch is the sequence length, and
-# the byte cap only bounds the transient allocation (0: always recompute)
-ATTN_DS_MAX_BYTES = 4096 << 20
-ATTN_DS_MAX_SEQLEN = 1536
+# The backward's dS^T scratch (dK / dV leaves dS^T behind, dQ is a plain product over it instead of a second recomputation of S and dP):
+# round 4 measured it faster at 785 / 456 tokens, equal at 2049 and slower at 4609 and switched on the sequence length (1536). Re-measured
+# inside the step at the end of round 5 (A B A B, profiles/r5_attn_ds_threshold_ab.txt) it wins at every length the workloads have:
+# phase-grg-3d (8 x 2049) 660.1 -> 656.2 ms, model-hr-2d (4 x 4097) 594.8 -> 585.9, model-hr-3d (4 x 4609) 827.7 -> 801.6, phase-vlm-mixed
+# 465.1 -> 463.4. The sequence limit is now only the kernels' 32-bit offset range; the byte cap bounds the transient allocation (2.8 GB at
+# 4 x 4609 x 16 heads; 0: always recompute).
+ATTN_DS_MAX_BYTES = 8192 << 20
+ATTN_DS_MAX_SEQLEN = 16384
 def _attn_args(q, k, v, out, lse, cu_seqlens, max_seqlen, n_heads, head_dim, scale, causal, row_of_pos, total_pos_max):
     a = hip.AttnArgs()
     a.q, a.k, a.v, a.out = ptr(q), ptr(k), ptr(v), ptr(out)
@@ -661,7 +664,7 @@ def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim,
     a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.delta = ptr(delta)
     # dS^T scratch (vm_attn_bwd_workspace_bytes): with it dQ is a product over what dK / dV left behind instead of a second recomputation.
-    # Freed on return: the caching allocator hands it out again in stream order. Long (3-D) sequences keep the recomputing dQ.
+    # Freed on return: the caching allocator hands it out again in stream order.
     need = C.c_int64(0)
     hip.call('vm_attn_bwd_workspace_bytes', C.addressof(a), C.addressof(need))
     ws = None

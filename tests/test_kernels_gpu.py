@@ -641,7 +641,8 @@ def test_attention_bf16_row_indirection(dev, K):
     assert torch.equal(g_phys[perm], g_seq)
 
 
-@pytest.mark.parametrize('hd,H,causal,lens', [(112, 2, False, [785, 33]), (128, 2, True, [456, 130, 1, 64]), (64, 3, False, [200]), (16, 1, True, [129])])
+@pytest.mark.parametrize('hd,H,causal,lens', [(112, 2, False, [785, 33]), (128, 2, True, [456, 130, 1, 64]), (64, 3, False, [200]), (16, 1, True, [129]),
+                                              (112, 2, False, [2049, 700]), (112, 1, False, [4609]), (128, 1, True, [3000, 1044])])      # (the 3-D / high-resolution lengths: on the workspace path since round 5b)
 def test_attention_backward_workspace_path_equals_recompute_path(dev, K, monkeypatch, hd, H, causal, lens):
     """with the dS^T scratch (vm_attn_bwd_workspace_bytes) dK / dV stores dS^T and dQ is a product over it; without it dQ recomputes
     S and dP. Same bf16 dS, same key order of the dQ sum: the two must agree bit for bit — ragged lengths, the causal mask, row indirection"""
