@@ -383,8 +383,18 @@ def apply_sets(sets) -> bool:
     forced = False
     for item in sets:
         path, _, val = item.partition('=')
-        mod, _, name = path.rpartition('.')
-        m = importlib.import_module('mmmm_amd.' + mod)
+        parts = path.split('.')
+        m, k = None, len(parts) - 1
+        while k > 0 and m is None:                 # the longest importable module prefix, then attributes (a class constant: models.mmmm.MMMMForCausalLM.concurrent_heads)
+            try:
+                m = importlib.import_module('mmmm_amd.' + '.'.join(parts[:k]))
+            except ImportError:
+                k -= 1
+        if m is None:
+            raise SystemExit(f'--set {item}: no module behind mmmm_amd.{path}')
+        for a in parts[k:-1]:
+            m = getattr(m, a)
+        mod, name = '.'.join(parts[:-1]), parts[-1]
         if not hasattr(m, name):
             raise SystemExit(f'--set {item}: mmmm_amd.{mod} has no attribute {name}')
         setattr(m, name, ast.literal_eval(val))
