@@ -370,6 +370,11 @@ int vm_transpose_segment(const void* in, int64_t ld_in, void* out, int64_t ld_ou
 int vm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int step, const float* clip_coef_dev, int dtype, void* stream);
 
+/* partials_out[b] = sum of x[i]^2 over workgroup b's share of the n elements (fp32 accumulation; n_partials workgroups, a fixed
+ * element -> workgroup map: deterministic). The gradient-norm side of gradient_clip_val (conf/phase-vg/fit.yaml:8-9; the reference's
+ * torch.nn.utils.clip_grad_norm_): the caller sums the partials of all buckets and takes the root. n % 8 == 0 (bf16) / % 4 (fp32). */
+int vm_sumsq_partials(const void* x, int64_t n, int dtype, float* partials_out, int n_partials, void* stream);
+
 /* out_accum[c] += sum_r x[r, c] (fp32, atomically accumulated: zero it first). Bias gradients. */
 int vm_colsum(const void* x, int64_t ld, float* out_accum, int rows, int cols, int dtype,
               const int32_t* nrows_dev, void* stream);

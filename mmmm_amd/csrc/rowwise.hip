@@ -692,6 +692,23 @@ __global__ __launch_bounds__(256) void adamw_k(T* __restrict__ p, const T* __res
   }
 }
 
+// ---------------------------------------------------------------- sum of squares (gradient norm): one partial per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_k(const T* __restrict__ x, int64_t n, float* __restrict__ partials) {
+  constexpr int V = Elem<T>::VEC;
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; i < n; i += (int64_t)gridDim.x * 256 * V) {
+    auto v = ldv<T>(x + i);
+#pragma unroll
+    for (int e = 0; e < V; ++e) { const float f = Elem<T>::ld(v[e]); acc = __builtin_fmaf(f, f, acc); }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---------------------------------------------------------------- column sums (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_k(const T* __restrict__ x, int64_t ld, float* __restrict__ out,
@@ -1109,6 +1126,15 @@ int vm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, floa
   const float rsqrt_bc2 = 1.0f / sqrtf(1.0f - powf(beta2, (float)step));
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(adamw_k<T>, dim3(ew_grid(n, vec)), dim3(256), 0, (hipStream_t)stream, (T*)p, (const T*)g,
                                            (T*)m, (T*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, rsqrt_bc2, clip_coef_dev));
+  VM_LAUNCH_CHECK();
+  return VM_OK;
+}
+
+int vm_sumsq_partials(const void* x, int64_t n, int dtype, float* partials_out, int n_partials, void* stream) {
+  if (!x || !partials_out || n < 0 || n_partials <= 0) return VM_ERR_BAD_ARG;
+  const int vec = dtype == VM_BF16 ? 8 : 4;
+  if (n % vec || !aligned16(x)) return VM_ERR_BAD_ARG;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sumsq_k<T>, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, (const T*)x, n, partials_out));
   VM_LAUNCH_CHECK();
   return VM_OK;
 }

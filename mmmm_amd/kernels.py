@@ -675,6 +675,12 @@ def attn_bwd(q, k, v, out, lse, dout, cu_seqlens, max_seqlen, n_heads, head_dim,
     return dqkv
 
 
+def sumsq_partials(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[b] = sum of squares of workgroup b's share of the flat tensor x (vm_sumsq_partials: fp32, deterministic)"""
+    assert x.is_contiguous() and out.dtype == torch.float32 and out.is_contiguous()
+    hip.call('vm_sumsq_partials', ptr(x), x.numel(), dtype_code(x.dtype), ptr(out), out.numel(), stream())
+
+
 def adamw_(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
            weight_decay: float = 1e-2, step: int, clip_coef: torch.Tensor | None = None):
     """in-place fused clip + AdamW over flat 1-D buffers of one dtype"""

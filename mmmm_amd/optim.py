@@ -64,6 +64,7 @@ class FlatAdamW:
                  max_grad_norm: float | None = None):
         self.ddp, self.lr, self.betas, self.eps, self.weight_decay = ddp, lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
+        self._sumsq = None               # [buckets, 1024] fp32 partial sums of squares (grad_norm_and_coef)
         ddp.defer_average = True          # finish() leaves the SUM over ranks; step() folds 1/world into the coefficient below
         self.step_count = 0
         self.last_lr = None
@@ -88,10 +89,14 @@ class FlatAdamW:
     @torch.no_grad()
     def grad_norm_and_coef(self):
         """global L2 norm of the bucketed gradients and the clip coefficient min(1, max_norm / (norm + 1e-6)) — device scalars"""
-        sq = None
-        for b in self.ddp.buckets:
-            v = torch.linalg.vector_norm(b.buffer, 2, dtype=torch.float32)
-            sq = v * v if sq is None else sq + v * v
+        # one streaming pass per bucket (vm_sumsq_partials: 1 024 per-workgroup partial sums each, a fixed element -> workgroup map), then ONE
+        # reduction over all partials: ~1.7 GB of gradients at the HBM rate instead of 15 `linalg.vector_norm` calls at 1.2 TB/s (0.76 ms): 305.8 -> 304.8 ms per step, A B A B
+        nb = len(self.ddp.buckets)
+        if self._sumsq is None or self._sumsq.shape[0] != nb:
+            self._sumsq = torch.empty(nb, 1024, dtype=torch.float32, device=self.ddp.buckets[0].buffer.device)
+        for i, b in enumerate(self.ddp.buckets):
+            K.sumsq_partials(b.buffer, self._sumsq[i])
+        sq = self._sumsq.sum(dtype=torch.float32)
         gs = float(self.ddp.grad_scale)               # 1/world pending from a deferred finish(): the buckets hold the SUM
         total = sq.sqrt() * gs                          # norm of the averaged gradient
         coef = torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0).reshape(1) * gs if self.max_grad_norm is not None else None

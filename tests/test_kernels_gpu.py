@@ -1196,3 +1196,19 @@ def test_mfma_peak_probe_returns_a_plausible_rate(dev, K):
     sustains between ~1.5 and 2.5 PFLOP/s there (nominal 2.5 at 2.4 GHz; the clock under matrix load is lower)"""
     r = K.ubench_mfma_bf16(0.4)
     assert 1000.0 < r < 2600.0, r
+
+
+@pytest.mark.parametrize('dtype,n', [(torch.bfloat16, 8 * 1000003), (torch.float32, 4 * 250007), (torch.bfloat16, 64)])
+def test_sumsq_partials_is_the_sum_of_squares_and_deterministic(dev, K, dtype, n):
+    """vm_sumsq_partials (the gradient-norm pass of FlatAdamW): the per-workgroup partials add up to sum x^2 (fp32 accumulation against an
+    fp64 reference) and two launches give the same bits (fixed element -> workgroup map, no atomics)"""
+    torch.manual_seed(3)
+    x = (torch.randn(n, device=dev) * 0.3).to(dtype)
+    a = torch.full((1024,), float('nan'), device=dev)
+    b = torch.full((1024,), float('nan'), device=dev)
+    K.sumsq_partials(x, a)
+    K.sumsq_partials(x, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    ref = x.double().pow(2).sum().item()
+    assert abs(a.double().sum().item() - ref) <= 2e-6 * ref
