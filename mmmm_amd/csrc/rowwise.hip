@@ -564,17 +564,49 @@ __global__ __launch_bounds__(256) void transpose_f32_vec_k(const float* __restri
 
 // one launch for a whole table of small transposes (every LoRA factor of the model after an optimizer step):
 // desc[i] = {src, dst, rows, cols, ld_src, ld_dst} as int64; blockIdx.y = table entry, blockIdx.x = 64x64 tile
+// 2-byte entries whose rows, columns and pitches are multiples of 8 and whose bases are 16-byte aligned (every LoRA factor) take the
+// vector path: 16-byte loads along the input rows, 16-byte stores along the output rows, the transposition in LDS (2 + 2 vector
+// accesses per thread and tile instead of 16 + 16 two-byte ones: 1 152 factors = 604 MB moved per step, 0.74 -> ~3 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_batched_k(const int64_t* __restrict__ desc) {
-  __shared__ T tile[64][64 + 2];
+  constexpr int PITCH = sizeof(T) == 2 ? 72 : 66;          // 144-byte rows keep the 16-byte LDS writes of the vector path aligned
+  __shared__ __attribute__((aligned(16))) T tile[64][PITCH];
   const int64_t* d = desc + (int64_t)blockIdx.y * 6;
   const T* in = reinterpret_cast<const T*>(d[0]);
   T* out = reinterpret_cast<T*>(d[1]);
   const int rows = (int)d[2], cols = (int)d[3];
   const int64_t ld_in = d[4], ld_out = d[5];
   const int tiles_c = (cols + 63) / 64, tiles_r = (rows + 63) / 64;
+  const bool vec = sizeof(T) == 2 && ((rows | cols) & 7) == 0 && ((ld_in | ld_out) & 7) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    if constexpr (sizeof(T) == 2) {
+      if (vec) {
+        typedef __attribute__((ext_vector_type(8))) unsigned short v8_t;
+        const int p = threadIdx.x >> 3, q = threadIdx.x & 7;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r = p + 32 * it;
+          v8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (r0 + r < rows && c0 + 8 * q < cols) v = *reinterpret_cast<const v8_t*>(in + (int64_t)(r0 + r) * ld_in + c0 + 8 * q);
+          *reinterpret_cast<v8_t*>(&tile[r][8 * q]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int oc = p + 32 * it;                          // output row = input column
+          if (c0 + oc < cols && r0 + 8 * q < rows) {
+            v8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(unsigned short, tile[8 * q + e][oc]);
+            *reinterpret_cast<v8_t*>(out + (int64_t)(c0 + oc) * ld_out + r0 + 8 * q) = v;
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
       const int r = r0 + i, c = c0 + tx;
