@@ -200,10 +200,11 @@ F32_TN_WGRAD = True
 # 0: ops asked to `fork` (hand their input back for the block's residual) return the input itself, i.e. autograd sums the two gradients of
 # the input with its own element-wise add (A/B measurements)
 FORK = True
-# the LINEAR form of the fork (post-norm ViT-E blocks: the residual's gradient rides in the dgrad GEMM's epilogue) is off by default: it
-# removes 126 element-wise adds per step but makes 126 dgrad GEMMs read one more [tokens, hidden] operand — step time equal
-# (342.4 vs 342.8 ms), dominant-GEMM rate 1 164 vs 1 178 TFLOP/s (A B A B in one call).
-FORK_LINEAR = False
+# the LINEAR form of the fork (post-norm ViT-E blocks: the residual's gradient rides in the dgrad GEMM's epilogue): removes 126 element-wise
+# adds per step and makes 126 dgrad GEMMs read one more [tokens, hidden] operand. A tie in rounds 2-4 (342.4 vs 342.8 ms) and at the start of
+# round 5 (299.8 vs 299.5); with the rest of the step tightened it is a small, repeatable gain — 299.15 -> 298.53 ms over three A B pairs in
+# one call (profiles/r5_fork_linear_ab.txt), the residual costs the epilogue 0.6-3 us where the add kernel takes 10.5 — so it is ON.
+FORK_LINEAR = True
 
 
 def _off_critical_path(fn, device, keep_alive):

@@ -311,8 +311,8 @@ def test_forked_norms_and_linear_sum_the_residual_gradient(dev, K, dt):
 
 
 def test_vit_layer_with_the_linear_fork_matches_the_default(dev, K, monkeypatch):
-    """functional.FORK_LINEAR (off by default): a post-norm ViT-E layer whose residual gradients ride in the dgrad GEMM epilogues gives the
-    same output and, up to one bf16 rounding per sum, the same gradients as the default (autograd's own adds)"""
+    """functional.FORK_LINEAR (on by default since round 5): a post-norm ViT-E layer whose residual gradients ride in the dgrad GEMM epilogues gives the
+    same output and, up to one bf16 rounding per sum, the same gradients as autograd's own adds"""
     from argparse import Namespace
     from mmmm_amd import functional as Fh
     from mmmm_amd.models.cogvlm.visual import TransformerLayer
