@@ -226,6 +226,167 @@ __global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_k(
   }
 }
 
+// ---------------------------------------------------------------- norms with the row held in registers
+// The kernels above walk a row two or three times with a run-time trip count, so every pass is a new trip to L1 / L2 (the rows of four waves
+// plus their neighbours do not stay in a 32 KiB L1). Rows of up to NV x 64 vectors (bf16: 2 048 / 4 096 columns for NV = 4 / 8, fp32: 1 024 /
+// 2 048) are loaded ONCE into NV vector registers per operand; the passes then run on registers. Same per-lane order of additions as the
+// generic kernels (column chunks ascending), so the results are bit-identical (tests/test_kernels_gpu.py: *_register_rows_*).
+#define VM_ROW_LOOP(j, c) _Pragma("unroll") for (int j = 0, c = lane * V; j < NV; ++j, c += 64 * V) if (c < cols)
+
+template <typename T, int NV>
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_fwd_r_k(
+    const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y, float* __restrict__ rstd_out,
+    int rows, int cols, float eps, const int32_t* nrows_dev) {
+  constexpr int V = Elem<T>::VEC;
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  T* yr = y + (int64_t)row * cols;
+  typename Elem<T>::vec_t xv[NV];
+  VM_ROW_LOOP(j, c) xv[j] = ldv<T>(xr + c);
+  float ss = 0.f;
+  VM_ROW_LOOP(j, c) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { float f = Elem<T>::ld(xv[j][i]); ss += f * f; }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = r;
+  VM_ROW_LOOP(j, c) {
+    auto wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = Elem<T>::st(Elem<T>::ld(wv[i]) * (Elem<T>::ld(xv[j][i]) * r));
+    stv<T>(yr + c, o);
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_bwd_r_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
+    const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols, const int32_t* nrows_dev,
+    const T* __restrict__ dx_add) {
+  constexpr int V = Elem<T>::VEC;
+  if (nrows_dev) rows = min(rows, *nrows_dev);
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  const T* dyr = dy + (int64_t)row * cols;
+  const T* addr = dx_add ? dx_add + (int64_t)row * cols : nullptr;
+  T* dxr = dx + (int64_t)row * cols;
+  const float r = rstd[row];
+  typename Elem<T>::vec_t xv[NV], gv[NV];
+  VM_ROW_LOOP(j, c) { xv[j] = ldv<T>(xr + c); gv[j] = ldv<T>(dyr + c); }
+  float dot = 0.f;
+  VM_ROW_LOOP(j, c) {
+    auto wv = ldv<T>(w + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) dot += Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[j][i]) * (Elem<T>::ld(xv[j][i]) * r);
+  }
+  dot = wave_sum(dot) / (float)cols;
+  VM_ROW_LOOP(j, c) {
+    auto wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o, av;
+    if (addr) av = ldv<T>(addr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float xh = Elem<T>::ld(xv[j][i]) * r;
+      o[i] = Elem<T>::st(r * (Elem<T>::ld(wv[i]) * Elem<T>::ld(gv[j][i]) - xh * dot) + (addr ? Elem<T>::ld(av[i]) : 0.f));
+    }
+    stv<T>(dxr + c, o);
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_fwd_r_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b, const T* __restrict__ res,
+    T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    int rows, int cols, float eps) {
+  constexpr int V = Elem<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  typename Elem<T>::vec_t xv[NV];
+  VM_ROW_LOOP(j, c) xv[j] = ldv<T>(xr + c);
+  float s = 0.f;
+  VM_ROW_LOOP(j, c) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += Elem<T>::ld(xv[j][i]);
+  }
+  const float mu = wave_sum(s) / (float)cols;
+  float ss = 0.f;
+  VM_ROW_LOOP(j, c) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { const float d = Elem<T>::ld(xv[j][i]) - mu; ss += d * d; }
+  }
+  const float r = rsqrtf(wave_sum(ss) / (float)cols + eps);
+  if (lane == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = r; }
+  T* yr = y + (int64_t)row * cols;
+  const T* rr = res ? res + (int64_t)row * cols : nullptr;
+  VM_ROW_LOOP(j, c) {
+    typename Elem<T>::vec_t o;
+    typename Elem<T>::vec_t wv, bv, rv;
+    if (w) wv = ldv<T>(w + c);
+    if (b) bv = ldv<T>(b + c);
+    if (rr) rv = ldv<T>(rr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float f = (Elem<T>::ld(xv[j][i]) - mu) * r;
+      if (w) f *= Elem<T>::ld(wv[i]);
+      if (b) f += Elem<T>::ld(bv[i]);
+      if (rr) f = Elem<T>::ld(Elem<T>::st(f)) + Elem<T>::ld(rv[i]);
+      o[i] = Elem<T>::st(f);
+    }
+    stv<T>(yr + c, o);
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(ROW_THREADS) void layernorm_bwd_r_k(
+    const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx, int rows, int cols,
+    const T* __restrict__ dx_add) {
+  constexpr int V = Elem<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROW_WAVES + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * cols;
+  const T* dyr = dy + (int64_t)row * cols;
+  const T* addr = dx_add ? dx_add + (int64_t)row * cols : nullptr;
+  T* dxr = dx + (int64_t)row * cols;
+  const float mu = mean[row], r = rstd[row];
+  typename Elem<T>::vec_t xv[NV], gv[NV];
+  VM_ROW_LOOP(j, c) { xv[j] = ldv<T>(xr + c); gv[j] = ldv<T>(dyr + c); }
+  float s1 = 0.f, s2 = 0.f;
+  VM_ROW_LOOP(j, c) {
+    typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float xh = (Elem<T>::ld(xv[j][i]) - mu) * r, g = Elem<T>::ld(gv[j][i]);
+      const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+      s1 += wg; s2 += wg * xh;
+    }
+  }
+  s1 = wave_sum(s1) / (float)cols; s2 = wave_sum(s2) / (float)cols;
+  VM_ROW_LOOP(j, c) {
+    typename Elem<T>::vec_t wv; if (w) wv = ldv<T>(w + c);
+    typename Elem<T>::vec_t o, av;
+    if (addr) av = ldv<T>(addr + c);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float xh = (Elem<T>::ld(xv[j][i]) - mu) * r, g = Elem<T>::ld(gv[j][i]);
+      const float wg = w ? Elem<T>::ld(wv[i]) * g : g;
+      o[i] = Elem<T>::st(r * (wg - s1 - xh * s2) + (addr ? Elem<T>::ld(av[i]) : 0.f));
+    }
+    stv<T>(dxr + c, o);
+  }
+}
+#undef VM_ROW_LOOP
+
 // ---------------------------------------------------------------- RoPE
 template <typename T>
 __global__ __launch_bounds__(ROW_THREADS) void rope_k(
@@ -869,6 +1030,15 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
   else if ((dtype) == VM_F32) { typedef float T; __VA_ARGS__; }       \
   else return VM_ERR_BAD_ARG;
 
+// rows that fit NV = 4 / 8 vectors per lane take the register form (internal switch for A/B runs and the equality tests)
+static int& norm_regs_on() { static int v = 1; return v; }
+extern "C" int vm_norm_register_rows_(int on) { norm_regs_on() = on ? 1 : 0; return VM_OK; }
+static inline int norm_nv(int cols, int vec) {
+  if (!norm_regs_on()) return 0;
+  const int n = (cols + 64 * vec - 1) / (64 * vec);
+  return n <= 4 ? 4 : (n <= 8 ? 8 : 0);
+}
+
 // bf16 tensors of >= 1 M elements go through the table kernels
 static int& gelu_table_on() { static int on = 1; return on; }
 extern "C" int vm_gelu_table_(int on) { gelu_table_on() = on ? 1 : 0; return VM_OK; }      // internal (tools/bench_gelu.py): 0 = always the arithmetic kernel
@@ -892,8 +1062,10 @@ int vm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows,
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(rmsnorm_fwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)w, (T*)y, rstd, rows, cols, eps, nrows_dev));
+  const int nv = norm_nv(cols, vec);
+#define VM_RMS_FWD(K) hipLaunchKernelGGL(K, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y, rstd, rows, cols, eps, nrows_dev)
+  DISPATCH_DTYPE(dtype, if (nv == 4) VM_RMS_FWD((rmsnorm_fwd_r_k<T, 4>)); else if (nv == 8) VM_RMS_FWD((rmsnorm_fwd_r_k<T, 8>)); else VM_RMS_FWD(rmsnorm_fwd_k<T>));
+#undef VM_RMS_FWD
   VM_LAUNCH_CHECK();
   return VM_OK;
 }
@@ -911,9 +1083,12 @@ int vm_rmsnorm_bwd_res(const void* x, const void* w, const void* dy, const float
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 255) / 256, (rows + 31) / 32);
+  const int nv = norm_nv(cols, vec);
+#define VM_RMS_BWD(K) hipLaunchKernelGGL(K, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev, (const T*)dx_add)
   DISPATCH_DTYPE(dtype,
-                 if (dx) hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                            (const T*)dy, rstd, (T*)dx, rows, cols, nrows_dev, (const T*)dx_add);
+                 if (dx) {
+                   if (nv == 4) VM_RMS_BWD((rmsnorm_bwd_r_k<T, 4>)); else if (nv == 8) VM_RMS_BWD((rmsnorm_bwd_r_k<T, 8>)); else VM_RMS_BWD(rmsnorm_bwd_k<T>);
+                 }
                  if (dw_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                                   (const T*)dy, (const float*)nullptr, rstd, dw_accum, (float*)nullptr, rows, cols,
                                                   nrows_dev));
@@ -927,9 +1102,10 @@ int vm_layernorm_fwd(const void* x, const void* w, const void* b, const void* re
   const int vec = dtype == VM_BF16 ? 8 : 4;
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(layernorm_fwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)w, (const T*)b, (const T*)residual, (T*)y, mean, rstd,
-                                           rows, cols, eps));
+  const int nv = norm_nv(cols, vec);
+#define VM_LN_FWD(K) hipLaunchKernelGGL(K, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (const T*)b, (const T*)residual, (T*)y, mean, rstd, rows, cols, eps)
+  DISPATCH_DTYPE(dtype, if (nv == 4) VM_LN_FWD((layernorm_fwd_r_k<T, 4>)); else if (nv == 8) VM_LN_FWD((layernorm_fwd_r_k<T, 8>)); else VM_LN_FWD(layernorm_fwd_k<T>));
+#undef VM_LN_FWD
   VM_LAUNCH_CHECK();
   return VM_OK;
 }
@@ -947,9 +1123,12 @@ int vm_layernorm_bwd_res(const void* x, const void* w, const void* dy, const flo
   if (cols % vec) return VM_ERR_BAD_ARG;
   dim3 grid((rows + ROW_WAVES - 1) / ROW_WAVES);
   dim3 gridw((cols + 255) / 256, (rows + 31) / 32);
+  const int nv = norm_nv(cols, vec);
+#define VM_LN_BWD(K) hipLaunchKernelGGL(K, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (const T*)dy, mean, rstd, (T*)dx, rows, cols, (const T*)dx_add)
   DISPATCH_DTYPE(dtype,
-                 if (dx) hipLaunchKernelGGL(layernorm_bwd_k<T>, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)w,
-                                            (const T*)dy, mean, rstd, (T*)dx, rows, cols, (const T*)dx_add);
+                 if (dx) {
+                   if (nv == 4) VM_LN_BWD((layernorm_bwd_r_k<T, 4>)); else if (nv == 8) VM_LN_BWD((layernorm_bwd_r_k<T, 8>)); else VM_LN_BWD(layernorm_bwd_k<T>);
+                 }
                  if (dw_accum || db_accum) hipLaunchKernelGGL(norm_bwd_dwdb_k<T>, gridw, dim3(256), 0, (hipStream_t)stream,
                                                               (const T*)x, (const T*)dy, mean, rstd, dw_accum, db_accum, rows, cols,
                                                               (const int32_t*)nullptr));

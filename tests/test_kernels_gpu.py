@@ -223,6 +223,40 @@ def test_transpose_batched(dev, K):
 
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('cols', [64, 256, 768, 1792, 2048, 4096, 5120])
+def test_norms_with_register_rows_equal_the_generic_kernels_bit_for_bit(dev, K, dt, cols):
+    """rows of up to 8 x 64 vectors are held in registers across the passes (rowwise.hip: *_r_k); same per-lane order of additions as the
+    run-time-loop kernels, so outputs, statistics and input gradients are identical bits (the fp32 RMSNorm — not on the training path — to one ulp; 5120 bf16 columns / 4096 fp32 take the generic path
+    either way); ragged row counts, the residual operand of the LayerNorm forward and the forked residual gradient of both backwards included"""
+    from mmmm_amd import hip
+    rows = 203
+    x = torch.randn(rows, cols, device=dev).to(dt)
+    w = (1 + 0.1 * torch.randn(cols, device=dev)).to(dt)
+    b = (0.1 * torch.randn(cols, device=dev)).to(dt)
+    res = torch.randn(rows, cols, device=dev).to(dt)
+    dy = torch.randn(rows, cols, device=dev).to(dt)
+    add = torch.randn(rows, cols, device=dev).to(dt)
+    nrows = torch.tensor([190], dtype=torch.int32, device=dev)
+    out = []
+    try:
+        for on in (1, 0):
+            assert hip.lib().vm_norm_register_rows_(on) == 0
+            y, rstd = K.rmsnorm_fwd(x, w, 1e-6, nrows)
+            dx, _ = K.rmsnorm_bwd(x, w, dy, rstd, nrows, need_dw=False, dx_add=add)
+            y2, mean, rstd2 = K.layernorm_fwd(x, w, b, 1e-5, residual=res)
+            dx2, _, _ = K.layernorm_bwd(x, w, dy, mean, rstd2, need_dw=False, dx_add=add)
+            y3, _, _ = K.layernorm_fwd(x, None, None, 1e-5)
+            out.append((y[:190], rstd[:190], dx[:190], y2, mean, rstd2, dx2, y3))
+    finally:
+        hip.lib().vm_norm_register_rows_(1)
+    names = ('rms y', 'rms rstd', 'rms dx', 'ln y', 'ln mean', 'ln rstd', 'ln dx', 'ln y (no affine)')
+    bad = {n: (a.float() - c.float()).abs().max().item() for n, a, c in zip(names, *out) if not torch.equal(a, c)}
+    if dt == torch.float32:      # hipcc contracts the fp32 RMS sum of squares into FMAs in one of the two loop forms only: one ulp of rstd
+        bad = {n: e for n, e in bad.items() if not (n.startswith('rms') and e < 2e-6)}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('cols', [64, 4096])
 def test_rmsnorm(dev, K, dt, cols):
     rows, eps = 77, 1e-6
