@@ -114,14 +114,25 @@ __global__ __launch_bounds__(256) void norm_bwd_dwdb_k(
   float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
   typedef T vec4_t __attribute__((ext_vector_type(4)));
   if (c < cols) {          // (cols % 4 == 0: a lane's four columns are all inside or all outside)
-    for (int r = r0 + wid; r < r1; r += 4) {
-      const vec4_t gv = *reinterpret_cast<const vec4_t*>(dy + (int64_t)r * cols + c);
-      const vec4_t xv = *reinterpret_cast<const vec4_t*>(x + (int64_t)r * cols + c);
-      const float mu = mean ? mean[r] : 0.f, rs = rstd[r];
+    // a wave's eight rows of the chunk are requested together (a run-time row loop issued one pair of loads per round trip); rows past the
+    // chunk's end re-read its first row and are not added. Same order of additions per lane as the loop.
+    vec4_t gv[8], xv[8];
+    float mu[8], rs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + wid + 4 * k < r1 ? r0 + wid + 4 * k : r0;
+      gv[k] = *reinterpret_cast<const vec4_t*>(dy + (int64_t)r * cols + c);
+      xv[k] = *reinterpret_cast<const vec4_t*>(x + (int64_t)r * cols + c);
+      mu[k] = mean ? mean[r] : 0.f;
+      rs[k] = rstd[r];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (r0 + wid + 4 * k >= r1) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float g = Elem<T>::ld(gv[i]);
-        aw[i] += g * ((Elem<T>::ld(xv[i]) - mu) * rs);
+        const float g = Elem<T>::ld(gv[k][i]);
+        aw[i] += g * ((Elem<T>::ld(xv[k][i]) - mu[k]) * rs[k]);
         ab[i] += g;
       }
     }
