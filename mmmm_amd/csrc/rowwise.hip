@@ -417,38 +417,53 @@ __global__ __launch_bounds__(ROW_THREADS) void rope_k(
   const int cph = half / V;                    // chunks per half head
   const int items = 2 * n_heads * cph;         // q and k
   T* base = qkv + (int64_t)row * ld;
-  for (int it = lane; it < items; it += 64) {
-    const int ch = it % cph;
-    const int head = (it / cph) % n_heads;
-    const int which = it / (cph * n_heads);    // 0 = q, 1 = k
-    T* p1 = base + (int64_t)which * n_heads * hd + head * hd + ch * V;
-    T* p2 = p1 + half;
-    auto a = ldv<T>(p1); auto b = ldv<T>(p2);
-    typename Elem<T>::vec_t oa, ob;
-    // table holds cat(freqs, freqs): entry i and i+half are equal, but keep both lookups literal; 16-byte table loads
-    float c1v[V], s1v[V], c2v[V], s2v[V];
+  // in place: the compiler must keep an iteration's loads behind the previous iteration's stores (same buffer), so a plain loop is one
+  // memory round trip per item — 8 per lane at 32 heads x 128. Four items' operands are requested before the first is rotated.
+  constexpr int U = 4;
+  for (int it0 = lane; it0 < items; it0 += 64 * U) {
+    typename Elem<T>::vec_t a[U], b[U];
+    T* p1[U];
 #pragma unroll
-    for (int i4 = 0; i4 < V; i4 += 4) {
-      *reinterpret_cast<f32x4_t*>(c1v + i4) = *reinterpret_cast<const f32x4_t*>(cr + ch * V + i4);
-      *reinterpret_cast<f32x4_t*>(s1v + i4) = *reinterpret_cast<const f32x4_t*>(sr + ch * V + i4);
-      *reinterpret_cast<f32x4_t*>(c2v + i4) = *reinterpret_cast<const f32x4_t*>(cr + half + ch * V + i4);
-      *reinterpret_cast<f32x4_t*>(s2v + i4) = *reinterpret_cast<const f32x4_t*>(sr + half + ch * V + i4);
+    for (int u = 0; u < U; ++u) {
+      const int it = it0 + 64 * u;
+      if (it >= items) continue;
+      const int ch = it % cph;
+      const int head = (it / cph) % n_heads;
+      const int which = it / (cph * n_heads);    // 0 = q, 1 = k
+      p1[u] = base + (int64_t)which * n_heads * hd + head * hd + ch * V;
+      a[u] = ldv<T>(p1[u]); b[u] = ldv<T>(p1[u] + half);
     }
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const float c1 = c1v[i], s1 = s1v[i], c2 = c2v[i], s2 = s2v[i];
-      const float x1 = Elem<T>::ld(a[i]), x2 = Elem<T>::ld(b[i]);
-      if (!inverse) {
-        // out = x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
-        oa[i] = Elem<T>::st(x1 * c1 - x2 * s1);
-        ob[i] = Elem<T>::st(x2 * c2 + x1 * s2);
-      } else {
-        // transposed map: dx1 = g1*c1 + g2*s2 ; dx2 = g2*c2 - g1*s1
-        oa[i] = Elem<T>::st(x1 * c1 + x2 * s2);
-        ob[i] = Elem<T>::st(x2 * c2 - x1 * s1);
+    for (int u = 0; u < U; ++u) {
+      const int it = it0 + 64 * u;
+      if (it >= items) continue;
+      const int ch = it % cph;
+      typename Elem<T>::vec_t oa, ob;
+      // table holds cat(freqs, freqs): entry i and i+half are equal, but keep both lookups literal; 16-byte table loads
+      float c1v[V], s1v[V], c2v[V], s2v[V];
+#pragma unroll
+      for (int i4 = 0; i4 < V; i4 += 4) {
+        *reinterpret_cast<f32x4_t*>(c1v + i4) = *reinterpret_cast<const f32x4_t*>(cr + ch * V + i4);
+        *reinterpret_cast<f32x4_t*>(s1v + i4) = *reinterpret_cast<const f32x4_t*>(sr + ch * V + i4);
+        *reinterpret_cast<f32x4_t*>(c2v + i4) = *reinterpret_cast<const f32x4_t*>(cr + half + ch * V + i4);
+        *reinterpret_cast<f32x4_t*>(s2v + i4) = *reinterpret_cast<const f32x4_t*>(sr + half + ch * V + i4);
       }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float c1 = c1v[i], s1 = s1v[i], c2 = c2v[i], s2 = s2v[i];
+        const float x1 = Elem<T>::ld(a[u][i]), x2 = Elem<T>::ld(b[u][i]);
+        if (!inverse) {
+          // out = x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
+          oa[i] = Elem<T>::st(x1 * c1 - x2 * s1);
+          ob[i] = Elem<T>::st(x2 * c2 + x1 * s2);
+        } else {
+          // transposed map: dx1 = g1*c1 + g2*s2 ; dx2 = g2*c2 - g1*s1
+          oa[i] = Elem<T>::st(x1 * c1 + x2 * s2);
+          ob[i] = Elem<T>::st(x2 * c2 - x1 * s1);
+        }
+      }
+      stv<T>(p1[u], oa); stv<T>(p1[u] + half, ob);
     }
-    stv<T>(p1, oa); stv<T>(p2, ob);
   }
 }
 
