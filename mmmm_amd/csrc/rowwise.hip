@@ -556,7 +556,21 @@ __global__ __launch_bounds__(512) void gelu_tab_k(const unsigned short* __restri
   const unsigned short* tf = reinterpret_cast<const unsigned short*>(tab_raw);
   const float* tg = reinterpret_cast<const float*>(tab_raw);
   const int64_t nv = n / 8;
-  for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 512) {
+  int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
+  if constexpr (!BWD) {
+    // the forward has ONE 16-byte load per lane and iteration: 24 waves per CU keep 24 KiB in flight where ~2 us of latency at the CU's share
+    // of the memory rate wants ~45 (the backward, two loads per iteration, streams at 6.3 TB/s; this loop ran at 5.2). Two vectors per trip.
+    const int64_t stride = (int64_t)gridDim.x * 512;
+    for (; i + stride < nv; i += 2 * stride) {
+      const u16x8_t h0 = ldv<unsigned short>(h + i * 8), h1 = ldv<unsigned short>(h + (i + stride) * 8);
+      u16x8_t o0, o1;
+      gelu_tab_fwd8(tf, h0, o0);
+      gelu_tab_fwd8(tf, h1, o1);
+      stv<unsigned short>(y + i * 8, o0);
+      stv<unsigned short>(y + (i + stride) * 8, o1);
+    }
+  }
+  for (; i < nv; i += (int64_t)gridDim.x * 512) {
     const u16x8_t hv = BWD ? ldv_nt<unsigned short>(h + i * 8) : ldv<unsigned short>(h + i * 8);
     u16x8_t dv;
     if (BWD) dv = ldv_nt<unsigned short>(dy + i * 8);
@@ -565,9 +579,9 @@ __global__ __launch_bounds__(512) void gelu_tab_k(const unsigned short* __restri
     else gelu_tab_fwd8(tf, hv, o);
     if (BWD) stv_nt<unsigned short>(y + i * 8, o); else stv<unsigned short>(y + i * 8, o);
   }
-  for (int64_t i = nv * 8 + (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) {
-    const float x = bf2f(h[i]);
-    y[i] = f2bf(BWD ? gelu_erf_grad(x) * bf2f(dy[i]) : gelu_erf(x));
+  for (int64_t t = nv * 8 + (int64_t)blockIdx.x * 512 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 512) {
+    const float x = bf2f(h[t]);
+    y[t] = f2bf(BWD ? gelu_erf_grad(x) * bf2f(dy[t]) : gelu_erf(x));
   }
 }
 
