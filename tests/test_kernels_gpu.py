@@ -1224,17 +1224,19 @@ def test_gelu_table_kernels_equal_the_arithmetic_kernels_on_every_bf16_value(dev
     assert torch.equal(K.gelu(xr)[-5:], K.gelu(xr[-5:].clone()))
     assert torch.equal(K.gelu_bwd(xr, dr)[-5:], K.gelu_bwd(xr[-5:].clone(), dr[-5:].clone()))
     # a tensor longer than two sweeps of the capped grid (768 workgroups x 512 lanes x 8) runs the forward's two-vectors-per-trip loop,
-    # its one-vector remainder and the scalar tail: every input value once more, against the arithmetic kernel
+    # its one-vector remainder (and many grid sweeps of the backward) and the scalar tail: every input value once more, against the arithmetic kernel
     from mmmm_amd import hip
     n = 2 * 768 * 512 * 8 + 77 * 4096 + 3
     xl = x.repeat(n // 65536 + 1)[:n].clone()
-    y_tab = K.gelu(xl)
+    dl = torch.randn(n, device=dev, generator=g).bfloat16()
+    y_tab, dx_tab = K.gelu(xl), K.gelu_bwd(xl, dl)
     try:
         assert hip.lib().vm_gelu_table_(0) == 0
-        y_ar = K.gelu(xl)
+        y_ar, dx_ar = K.gelu(xl), K.gelu_bwd(xl, dl)
     finally:
         hip.lib().vm_gelu_table_(1)
     assert torch.equal(y_tab.view(torch.int16), y_ar.view(torch.int16))
+    assert torch.equal(dx_tab.view(torch.int16), dx_ar.view(torch.int16))
 
 
 def test_mfma_peak_probe_returns_a_plausible_rate(dev, K):
