@@ -504,7 +504,11 @@ int vm_attn_decode_bf16(const void* q, int64_t ldq, const void* k_cache, const v
 
 /* fp32 attention (SAM ViT-B encoder image_encoder.py:126-136 hd 64; two-way
  * transformer transformer.py:224-239 hd 96/48, tiny Lq or tiny Lk).
- * Dense batched form: q [Bn, Lq, H, hd], k/v [Bn, Lk, H, hd] given by strides. */
+ * Dense batched form: q [Bn, Lq, H, hd], k/v [Bn, Lk, H, hd] given by strides.
+ * Also the attention of the towers' fp32 ("32-true") mode — the reference's own precision for BASELINE configs[0]
+ * (mmmm.py:468-492 MyPrecision is optional): EVA-ViT-E visual.py:91-99 (hd 112, block-diagonal) and the decoder
+ * modeling_cogvlm.py:106-128 (hd 128, `causal`, positions mapped to the packed expert-sorted rows through `row_of_pos`
+ * exactly as vm_attn_*_bf16 does). head_dim in {8, 16, 32, 48, 64, 96, 112, 128}. */
 typedef struct vm_attn_f32_args {
   const float* q; const float* k; const float* v; float* out;
   int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;   /* batch / position strides (elements); head stride = hd */
@@ -519,6 +523,10 @@ typedef struct vm_attn_f32_args {
   int32_t f32_split;       /* arithmetic of the four products (head_dim 64 only; other head dims always take the exact form):
                               0 / 1 = exact f32 MFMA (v_mfma_f32_32x32x2_f32), 2 = split-bf16 with 3 products (~2^-17 per product),
                               3 = split-bf16 with 6 products (fp32 products) on v_mfma_f32_32x32x16_bf16 — cf. vm_gemm_args.f32_split */
+  /* packed self-attention (cu_seqlens given) in the exact arithmetic only; VM_ERR_BAD_ARG otherwise: */
+  int32_t causal;          /* key position <= query position within a sequence */
+  const int32_t* row_of_pos;   /* optional [cu_seqlens[n_seq]]: physical row (of q, k, v, out, dout, dq, dk, dv) of sequence position
+                              cu_seqlens[b] + i — vm_expert_index_build's table; lse / delta stay indexed by position */
 } vm_attn_f32_args;
 int vm_attn_fwd_f32(const vm_attn_f32_args* args_host, void* stream);
 int vm_attn_bwd_f32(const vm_attn_f32_args* args_host, void* stream);

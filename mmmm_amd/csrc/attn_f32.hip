@@ -156,19 +156,27 @@ struct AP {
   const float* dout; int64_t do_bs, do_ls;
   float* dq; float* dk; float* dv;
   float* delta;
+  // fp32 towers (exact form only): causal mask over sequence positions; position -> physical row of the packed operands
+  int causal;
+  const int32_t* rop;
 };
 
-struct Seq { int64_t qo, ko, vo, oo, doo; int lq, lk, stat0; };
+struct Seq { int64_t qo, ko, vo, oo, doo; int lq, lk, stat0; const int32_t* rop; };
 
 // per-(batch or sequence) base offsets and lengths
 __device__ __forceinline__ Seq seq_of(const AP& p, int b) {
   Seq s;
+  s.rop = nullptr;
   if (p.cu) {
     const int s0 = p.cu[b], s1 = p.cu[b + 1];
     s.lq = s.lk = s1 - s0;
     s.qo = (int64_t)s0 * p.q_ls; s.ko = (int64_t)s0 * p.k_ls; s.vo = (int64_t)s0 * p.v_ls;
     s.oo = (int64_t)s0 * p.o_ls; s.doo = (int64_t)s0 * p.do_ls;
     s.stat0 = s0;
+    if (p.rop) {                 // indirect layout: position i of this sequence lives in row rop[s0 + i] of every operand
+      s.rop = p.rop + s0;
+      s.qo = s.ko = s.vo = s.oo = s.doo = 0;
+    }
   } else {
     s.lq = p.Lq; s.lk = p.Lk;
     s.qo = (int64_t)b * p.q_bs; s.ko = (int64_t)b * p.k_bs; s.vo = (int64_t)b * p.v_bs;
@@ -183,15 +191,19 @@ __device__ __forceinline__ int64_t stat_idx(const AP& p, int head, int stat0, in
   return (int64_t)head * total + stat0 + pos;
 }
 
+__device__ __forceinline__ int64_t prow(const Seq& s, int pos) { return s.rop ? (int64_t)s.rop[pos] : (int64_t)pos; }
+
 // Stage ROWS x HD floats of a [pos][H][HD] operand into LDS with pitch PITCH (odd => conflict-free column reads).
 template <int HD, int HDP, int ROWS, int PITCH>
-__device__ __forceinline__ void stage(const float* base, int64_t ls, int head, int pos0, int len, float* tile, int tid) {
+__device__ __forceinline__ void stage(const float* base, int64_t ls, int head, int pos0, int len, float* tile, int tid,
+                                      const int32_t* rop = nullptr) {
   constexpr int PER_ROW = HDP / 4;
   for (int c = tid; c < ROWS * PER_ROW; c += 256) {
     const int row = c / PER_ROW, ch = c % PER_ROW;
     f32x4_t v = {0.f, 0.f, 0.f, 0.f};
     const int pos = pos0 + row;
-    if (pos < len && ch * 4 < HD) v = *reinterpret_cast<const f32x4_t*>(base + (int64_t)pos * ls + head * HD + ch * 4);
+    if (pos < len && ch * 4 < HD)
+      v = *reinterpret_cast<const f32x4_t*>(base + (rop ? (int64_t)rop[pos] : (int64_t)pos) * ls + head * HD + ch * 4);
     float* d = tile + row * PITCH + ch * 4;
     d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
   }
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
   if (q0 >= sq.lq) return;
   const int qpos = q0 + wave * 32 + (lane & 31);
   const bool qvalid = qpos < sq.lq;
-  const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
+  const float* qrow = p.q + sq.qo + prow(sq, qvalid ? qpos : 0) * p.q_ls + head * HD;
   float qf[NS > 0 ? 1 : KS];
   bf16x8_t qs[KB][NSS];
   if constexpr (NS > 0) {
@@ -237,7 +249,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
     for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
   const float sc = p.scale * LOG2E;
-  const int nt = (sq.lk + 31) / 32;
+  const bool causal = NS == 0 && p.causal;        // (the towers' fp32 mode; self-attention: key position <= query position)
+  const int nt = causal ? (min(sq.lk, q0 + 128) + 31) / 32 : (sq.lk + 31) / 32;
   f32x4_t gk[NS > 0 ? HD / 32 : 1], gv[NS > 0 ? HD / 32 : 1];      // split path: the next tile's rows, in flight during the current tile
   if constexpr (NS > 0) {
     tile_load<HD>(p.k + sq.ko, p.k_ls, head, 0, sq.lk, gk, tid);
@@ -250,8 +263,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
       tile_store<HD, NSS, true, false>(gk, pK, nullptr, tid);
       tile_store<HD, NSS, false, true>(gv, nullptr, pVt, tid);
     } else {
-      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
-      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid, sq.rop);
+      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid, sq.rop);
     }
     __syncthreads();
     if constexpr (NS > 0) {
@@ -276,7 +289,15 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
         sa = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(lane & 31) * PITCH + 2 * s + h], qf[s], sa, 0, 0, 0);
     }
     float mx = NEG_BIG;
-    if (kv0 + 32 > sq.lk) {                       // only the last tile can reach past the keys (wave-uniform branch)
+    if (causal && kv0 + 32 > q0 + wave * 32) {    // the tile reaches past this wave's first query: mask by position
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kvpos = kv0 + acc_row(r, h);
+        const float x = (kvpos < sq.lk && kvpos <= qpos) ? sa[r] * sc : NEG_BIG;
+        sa[r] = x;
+        mx = fmaxf(mx, x);
+      }
+    } else if (kv0 + 32 > sq.lk) {                // only the last tile can reach past the keys (wave-uniform branch)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float x = kv0 + acc_row(r, h) < sq.lk ? sa[r] * sc : NEG_BIG;
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 3 : 1) void attn_f32_fwd_k(const AP 
   if (!qvalid) return;
   const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
   if (h == 0 && p.lse) p.lse[stat_idx(p, head, sq.stat0, qpos)] = (m_run + log2f(l_run)) * LN2;
-  float* orow = p.out + sq.oo + (int64_t)qpos * p.o_ls + head * HD;
+  float* orow = p.out + sq.oo + prow(sq, qpos) * p.o_ls + head * HD;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -347,8 +368,8 @@ __global__ __launch_bounds__(256) void attn_f32_delta_k(const AP p) {
   const Seq sq = seq_of(p, blockIdx.z);
   const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= sq.lq) return;
-  const float* a = p.dout + sq.doo + (int64_t)pos * p.do_ls + head * HD;
-  const float* b = p.out + sq.oo + (int64_t)pos * p.o_ls + head * HD;
+  const float* a = p.dout + sq.doo + prow(sq, pos) * p.do_ls + head * HD;
+  const float* b = p.out + sq.oo + prow(sq, pos) * p.o_ls + head * HD;
   float acc = 0.f;
   for (int d = lane; d < HD; d += 64) acc += a[d] * b[d];
   acc = wave_sum(acc);
@@ -380,8 +401,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
   if (q0 >= sq.lq) return;
   const int qpos = q0 + wave * 32 + (lane & 31);
   const bool qvalid = qpos < sq.lq;
-  const float* qrow = p.q + sq.qo + (int64_t)(qvalid ? qpos : 0) * p.q_ls + head * HD;
-  const float* dorow = p.dout + sq.doo + (int64_t)(qvalid ? qpos : 0) * p.do_ls + head * HD;
+  const float* qrow = p.q + sq.qo + prow(sq, qvalid ? qpos : 0) * p.q_ls + head * HD;
+  const float* dorow = p.dout + sq.doo + prow(sq, qvalid ? qpos : 0) * p.do_ls + head * HD;
   float qf[NS > 0 ? 1 : KS], dof[NS > 0 ? 1 : KS];
   bf16x8_t qs[KB][NSS], dos[KB][NSS];
   if constexpr (NS > 0) {
@@ -399,7 +420,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[b][r] = 0.f;
-  const int nt = (sq.lk + 31) / 32;
+  const bool causal = NS == 0 && p.causal;
+  const int nt = causal ? (min(sq.lk, q0 + 128) + 31) / 32 : (sq.lk + 31) / 32;
   f32x4_t gk[NS > 0 ? HD / 32 : 1], gv[NS > 0 ? HD / 32 : 1];
   if constexpr (NS > 0) {
     tile_load<HD>(p.k + sq.ko, p.k_ls, head, 0, sq.lk, gk, tid);
@@ -412,8 +434,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
       tile_store<HD, NSS, true, true>(gk, pK, pKt, tid);
       tile_store<HD, NSS, true, false>(gv, pV, nullptr, tid);
     } else {
-      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid);
-      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid);
+      stage<HD, HDP, 32, PITCH>(p.k + sq.ko, p.k_ls, head, kv0, sq.lk, sK, tid, sq.rop);
+      stage<HD, HDP, 32, PITCH>(p.v + sq.vo, p.v_ls, head, kv0, sq.lk, sV, tid, sq.rop);
     }
     __syncthreads();
     if constexpr (NS > 0) {
@@ -441,11 +463,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(lane & 31) * PITCH + 2 * s + h], dof[s], dp, 0, 0, 0);
       }
     }
-    if (kv0 + 32 > sq.lk || !qvalid) {            // the last key tile, or a query row past the sequence (its lanes' lse2 is not a statistic)
+    if (kv0 + 32 > sq.lk || !qvalid || (causal && kv0 + 32 > q0 + wave * 32)) {   // the last key tile, a query row past the sequence (its lanes' lse2 is not a statistic), the causal diagonal
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kvpos = kv0 + acc_row(r, h);
-        const float pr = (kvpos < sq.lk && qvalid) ? fexp2(sa[r] * sc - lse2) : 0.f;
+        const float pr = (kvpos < sq.lk && qvalid && (!causal || kvpos <= qpos)) ? fexp2(sa[r] * sc - lse2) : 0.f;
         sa[r] = pr * (dp[r] - dlt) * p.scale;
       }
     } else {
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dq_k(const AP p
     }
   }
   if (!qvalid) return;
-  float* drow = p.dq + sq.qo + (int64_t)qpos * p.q_ls + head * HD;
+  float* drow = p.dq + sq.qo + prow(sq, qpos) * p.q_ls + head * HD;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -510,8 +532,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP 
   if (k0 >= sq.lk) return;
   const int kpos = k0 + wave * 32 + (lane & 31);
   const bool kvalid = kpos < sq.lk;
-  const float* krow = p.k + sq.ko + (int64_t)(kvalid ? kpos : 0) * p.k_ls + head * HD;
-  const float* vrow = p.v + sq.vo + (int64_t)(kvalid ? kpos : 0) * p.v_ls + head * HD;
+  const float* krow = p.k + sq.ko + prow(sq, kvalid ? kpos : 0) * p.k_ls + head * HD;
+  const float* vrow = p.v + sq.vo + prow(sq, kvalid ? kpos : 0) * p.v_ls + head * HD;
   float kf[NS > 0 ? 1 : KS], vf[NS > 0 ? 1 : KS];
   bf16x8_t ks[KB][NSS], vs[KB][NSS];
   if constexpr (NS > 0) {
@@ -527,21 +549,23 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP 
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[b][r] = 0.f; dv[b][r] = 0.f; }
+  const bool causal = NS == 0 && p.causal;
   const int nt = (sq.lq + 31) / 32;
+  const int t_first = causal ? k0 / 32 : 0;       // queries in front of this workgroup's first key see none of its keys
   f32x4_t gq[NS > 0 ? HD / 32 : 1], gd[NS > 0 ? HD / 32 : 1];
   if constexpr (NS > 0) {
     tile_load<HD>(p.q + sq.qo, p.q_ls, head, 0, sq.lq, gq, tid);
     tile_load<HD>(p.dout + sq.doo, p.do_ls, head, 0, sq.lq, gd, tid);
   }
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t_first; t < nt; ++t) {
     const int qq0 = t * 32;
     __syncthreads();
     if constexpr (NS > 0) {
       tile_store<HD, NSS, true, true>(gq, pQ, pQt, tid);
       tile_store<HD, NSS, true, true>(gd, pDO, pDOt, tid);
     } else {
-      stage<HD, HDP, 32, PITCH>(p.q + sq.qo, p.q_ls, head, qq0, sq.lq, sQ, tid);
-      stage<HD, HDP, 32, PITCH>(p.dout + sq.doo, p.do_ls, head, qq0, sq.lq, sDO, tid);
+      stage<HD, HDP, 32, PITCH>(p.q + sq.qo, p.q_ls, head, qq0, sq.lq, sQ, tid, sq.rop);
+      stage<HD, HDP, 32, PITCH>(p.dout + sq.doo, p.do_ls, head, qq0, sq.lq, sDO, tid, sq.rop);
     }
     if (tid < 32) {
       const int qp = qq0 + tid;
@@ -577,7 +601,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, h);
-      const bool vis = kvalid && (qq0 + qi) < sq.lq;
+      const bool vis = kvalid && (qq0 + qi) < sq.lq && (!causal || kpos <= qq0 + qi);
       const float pr = vis ? fexp2(sa[r] * sc - sLse[qi]) : 0.f;
       pa[r] = pr;
       sa[r] = pr * (dp[r] - sDlt[qi]) * p.scale;
@@ -608,8 +632,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void attn_f32_dkv_k(const AP 
     }
   }
   if (!kvalid) return;
-  float* dkrow = p.dk + sq.ko + (int64_t)kpos * p.k_ls + head * HD;
-  float* dvrow = p.dv + sq.vo + (int64_t)kpos * p.v_ls + head * HD;
+  float* dkrow = p.dk + sq.ko + prow(sq, kpos) * p.k_ls + head * HD;
+  float* dvrow = p.dv + sq.vo + prow(sq, kpos) * p.v_ls + head * HD;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -631,6 +655,7 @@ AP to_ap(const vm_attn_f32_args* a) {
   p.scale = a->scale; p.cu = a->cu_seqlens;
   p.dout = a->dout; p.do_bs = a->do_bs; p.do_ls = a->do_ls;
   p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
+  p.causal = a->causal; p.rop = a->row_of_pos;
   return p;
 }
 
@@ -639,6 +664,8 @@ bool ok(const vm_attn_f32_args* a) {
   if (a->n_heads <= 0 || a->Lq <= 0 || a->Lk <= 0) return false;
   if (a->cu_seqlens ? a->n_seq <= 0 : a->Bn <= 0) return false;
   if (a->q_ls % 4 || a->k_ls % 4 || a->v_ls % 4 || a->o_ls % 4) return false;
+  // causal / row_of_pos: packed self-attention in the exact arithmetic (the towers' fp32 mode)
+  if ((a->causal || a->row_of_pos) && (!a->cu_seqlens || (a->f32_split >= 2 && a->head_dim == 64))) return false;
   return true;
 }
 
@@ -647,6 +674,7 @@ bool ok(const vm_attn_f32_args* a) {
 #define F32_DISPATCH_HD(hd, ...)                                  \
   switch (hd) {                                                   \
     case 128: { constexpr int HD = 128; __VA_ARGS__; break; }     \
+    case 112: { constexpr int HD = 112; __VA_ARGS__; break; }     \
     case 96:  { constexpr int HD = 96;  __VA_ARGS__; break; }     \
     case 64:  { constexpr int HD = 64;  __VA_ARGS__; break; }     \
     case 48:  { constexpr int HD = 48;  __VA_ARGS__; break; }     \

@@ -784,7 +784,13 @@ class _Attention(Function):
 def attention(qkv, cu_seqlens, max_seqlen: int, n_heads: int, head_dim: int, scale: float, causal: bool,
               row_of_pos=None, total_pos_max: int | None = None, rope=None):
     """qkv: [rows, 3*H*hd] packed (q | k | v) -> [rows, H*hd]. `rope` = (row_pos, cos, sin, nrows): rotate q / k in place first (and
-    un-rotate the gradient in the backward) — `rope_` + `attention` in one autograd node"""
+    un-rotate the gradient in the backward) — `rope_` + `attention` in one autograd node.
+    fp32 qkv (the towers' "32-true" mode, reference mmmm.py:468-492 without MyPrecision): the exact-f32 kernels of the fp32 islands,
+    head widths 112 / 128, causal mask and the packed layout's position table included (vm_attn_*_f32)."""
+    if qkv.dtype == torch.float32:
+        if rope is not None:
+            qkv = rope_(qkv, *rope[:3], n_heads, head_dim, rope[3])
+        return self_attention_f32(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, 1, causal, row_of_pos)
     if rope is not None:
         return _Attention.call(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max, tuple(rope))[0]
     return _Attention.call(qkv, cu_seqlens, row_of_pos, max_seqlen, n_heads, head_dim, scale, causal, total_pos_max)
@@ -816,34 +822,37 @@ class _SelfAttentionF32(Function):
     both directions and the gradient is ONE dqkv tensor written in place by the kernels — no contiguous copies of the
     thirds, no zero-filled slice gradients, no accumulation adds."""
     @staticmethod
-    def forward(ctx, qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split=0):
+    def forward(ctx, qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split=0, causal=False, row_of_pos=None):
         Cw = n_heads * head_dim
         qkv = qkv if qkv.stride(-1) == 1 else qkv.contiguous()
         out, lse = K.attn_f32_fwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], n_heads, head_dim, scale, cu_seqlens, max_seqlen,
-                                  f32_split=f32_split)
-        ctx.save_for_backward(qkv, out, lse, cu_seqlens)
-        ctx.cfg = (n_heads, head_dim, scale, max_seqlen, f32_split)
+                                  f32_split=f32_split, causal=causal, row_of_pos=row_of_pos)
+        ctx.save_for_backward(qkv, out, lse, cu_seqlens, row_of_pos)
+        ctx.cfg = (n_heads, head_dim, scale, max_seqlen, f32_split, causal)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        qkv, out, lse, cu = ctx.saved_tensors
-        n_heads, head_dim, scale, max_seqlen, f32_split = ctx.cfg
+        qkv, out, lse, cu, rop = ctx.saved_tensors
+        n_heads, head_dim, scale, max_seqlen, f32_split, causal = ctx.cfg
         Cw = n_heads * head_dim
-        dqkv = torch.empty_like(qkv)      # every row belongs to a sequence: the dq / dkv kernels write all of it
+        # every row belongs to a sequence: the dq / dkv kernels write all of it (not so in the indirect layout: rows past the valid ones)
+        dqkv = torch.empty_like(qkv) if rop is None else torch.zeros_like(qkv)
         K.attn_f32_bwd(qkv[:, :Cw], qkv[:, Cw:2 * Cw], qkv[:, 2 * Cw:], out, lse, dout, n_heads, head_dim, scale, cu, max_seqlen,
-                       grads=(dqkv[:, :Cw], dqkv[:, Cw:2 * Cw], dqkv[:, 2 * Cw:]), f32_split=f32_split)
-        return dqkv, None, None, None, None, None, None
+                       grads=(dqkv[:, :Cw], dqkv[:, Cw:2 * Cw], dqkv[:, 2 * Cw:]), f32_split=f32_split, causal=causal, row_of_pos=rop)
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen, f32_split: int = 0):
+def self_attention_f32(qkv, n_heads: int, head_dim: int, scale: float, cu_seqlens, max_seqlen, f32_split: int = 0,
+                       causal: bool = False, row_of_pos=None):
     """`f32_split` (head_dim 64): arithmetic of the attention products — 0 exact f32 MFMA, 2 / 3 split-bf16 with 3 / 6 products
-    (kernels.attn_f32_fwd); the image encoders pass their blocks' `f32_split` (image_encoder.ENCODER_F32_SPLIT)"""
-    return _SelfAttentionF32.call(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split)
+    (kernels.attn_f32_fwd); the image encoders pass their blocks' `f32_split` (image_encoder.ENCODER_F32_SPLIT).
+    `causal` / `row_of_pos`: the towers' fp32 mode (exact arithmetic)"""
+    return _SelfAttentionF32.call(qkv, n_heads, head_dim, scale, cu_seqlens, max_seqlen, f32_split, causal, row_of_pos)
 
 
-_F32_HEAD_DIMS = (8, 16, 32, 48, 64, 96, 128)       # instantiations of attn_f32_*_k (csrc/attn_f32.hip)
+_F32_HEAD_DIMS = (8, 16, 32, 48, 64, 96, 112, 128)       # instantiations of attn_f32_*_k (csrc/attn_f32.hip)
 
 
 def attention_f32(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen=None):

@@ -82,6 +82,7 @@ class AttnF32Args(C.Structure):
         ('dq', C.c_void_p), ('dk', C.c_void_p), ('dv', C.c_void_p),
         ('delta', C.c_void_p),
         ('f32_split', C.c_int32),
+        ('causal', C.c_int32), ('row_of_pos', C.c_void_p),
     ]
 
 

@@ -878,21 +878,25 @@ def _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens):
     return a
 
 
-def attn_f32_fwd(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None, f32_split: int = 0):
+def attn_f32_fwd(q, k, v, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None, f32_split: int = 0,
+                 causal: bool = False, row_of_pos: torch.Tensor | None = None):
+    """`causal` / `row_of_pos` (packed self-attention, exact arithmetic): the towers' fp32 mode — see vm_attn_f32_args"""
     assert q.dtype == torch.float32 and q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
-    out = torch.empty(*q.shape[:-1], n_heads * head_dim, dtype=q.dtype, device=q.device)
+    # (indirect layout: rows that belong to no sequence are never written — zero them, the caller's row-wise kernels may still pass over them)
+    out = (torch.zeros if row_of_pos is not None else torch.empty)(*q.shape[:-1], n_heads * head_dim, dtype=q.dtype, device=q.device)
     n_q = q.shape[0] if cu_seqlens is not None else q.shape[0] * q.shape[1]
     lse = torch.empty(n_heads, n_q, dtype=torch.float32, device=q.device)
     a = _attn_f32_args(q, k, v, out, lse, n_heads, head_dim, scale, cu_seqlens)
     if cu_seqlens is not None and max_seqlen is not None:
         a.Lq = a.Lk = max_seqlen
     a.f32_split = f32_split          # head_dim 64 only: 2 / 3 = split-bf16 products (3 / 6 MFMAs), else the exact f32 MFMA chain
+    a.causal, a.row_of_pos = int(causal), ptr(row_of_pos)
     hip.call('vm_attn_fwd_f32', C.addressof(a), stream())
     return out, lse
 
 
 def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: float, cu_seqlens=None, max_seqlen: int | None = None,
-                 grads=None, f32_split: int = 0):
+                 grads=None, f32_split: int = 0, causal: bool = False, row_of_pos: torch.Tensor | None = None):
     """`grads`: optional (dq, dk, dv) destinations with the SAME strides as q / k / v (the kernel addresses them with the
     operands' strides), e.g. the thirds of one packed dqkv"""
     dout = _c(dout)
@@ -915,5 +919,6 @@ def attn_f32_bwd(q, k, v, out, lse, dout, n_heads: int, head_dim: int, scale: fl
     delta = torch.empty_like(lse)
     a.dout, a.dq, a.dk, a.dv, a.delta = ptr(dout), ptr(dq), ptr(dk), ptr(dv), ptr(delta)
     a.f32_split = f32_split
+    a.causal, a.row_of_pos = int(causal), ptr(row_of_pos)
     hip.call('vm_attn_bwd_f32', C.addressof(a), stream())
     return dq, dk, dv

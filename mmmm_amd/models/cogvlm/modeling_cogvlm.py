@@ -372,7 +372,11 @@ class _LMHeadCE(torch.autograd.Function):
             else:
                 dh = K.gemm(d, Wt)
         if ctx.needs_input_grad[1]:
-            dW = K.gemm_tn(d[:, :V], hc, nrows=n_lab)
+            if d.dtype == torch.bfloat16:
+                dW = K.gemm_tn(d[:, :V], hc, nrows=n_lab)
+            else:
+                # fp32 towers: K-contiguous transposes (zero beyond the labelled rows) feed the NT kernel, as the fp32 islands' linears do
+                dW = K.gemm(K.transpose(d[:, :V], pad_to=64, nrows=n_lab), K.transpose(hc, pad_to=64, nrows=n_lab))
         return dh, dW, None, None, None
 
 

@@ -37,7 +37,8 @@ def test_struct_layouts_match_header_sizes(library):
     assert ctypes.sizeof(hip.GemmArgs) % 8 == 0
     assert hip.GemmArgs.lda.offset == 8 and hip.GemmArgs.B.offset == 16
     assert ctypes.sizeof(hip.AttnArgs) % 8 == 0
-    assert ctypes.sizeof(hip.AttnF32Args) == 208 and hip.AttnF32Args.f32_split.offset == 200 and hip.AttnF32Args.delta.offset == 192
+    assert ctypes.sizeof(hip.AttnF32Args) == 216 and hip.AttnF32Args.f32_split.offset == 200 and hip.AttnF32Args.delta.offset == 192
+    assert hip.AttnF32Args.causal.offset == 204 and hip.AttnF32Args.row_of_pos.offset == 208
 
 
 def test_version(library):

@@ -1,0 +1,203 @@
+"""The towers' fp32 ("32-true") mode: north_star's tolerance asserted LITERALLY — logits within 1e-3 relative of the reference path.
+
+BASELINE configs[0] runs the reference in fp32 (`MyPrecision`, mmmm/models/mmmm.py:468-492, is optional: scripts/cli.py only installs it
+for bf16-true training); every other parity test of the language / vision towers is a bf16-true comparison, where NO evaluation — the
+reference's own included — gets closer than ~1e-2 to the fp32 result and the assertion has to be the evidence-based e_ref rule. Here the
+HIP model is built and run in fp32 end to end:
+
+  * every linear (gated experts, LoRA extension, lm_head) on `vm_gemm_f32` (six-product split-bf16 MFMA: 24-bit products, fp32 accumulate),
+  * RMSNorm / LayerNorm / RoPE / SiLU·up / GELU / CE / embedding on the fp32 instantiations of the row-wise kernels,
+  * attention on `vm_attn_fwd/bwd_f32` in the exact f32 MFMA form: head width 112 block-diagonal (EVA-ViT-E, visual.py:91-99) and head
+    width 128 causal over the packed expert-sorted rows (`row_of_pos`; decoder, modeling_cogvlm.py:106-128),
+
+and compared with the fp32 oracle (rope tables in fp32, as the reference builds them when the module is fp32):
+
+  1. tiny model (2 + 2 layers, widths 128, three images incl. 3-D, ragged text): loss, logits, every hidden state <= 1e-3 (expected ~1e-6),
+     every trainable parameter's gradient <= 1e-3 — forward AND backward of the mode;
+  2. BASELINE configs[0] at the TRUE widths (4096 / 11008 / 32 x 128, ViT-E 1792 / 15360 / 16 x 112, vocabulary 32 008), 2 + 2 layers:
+     logits on valid rows <= 1e-3 — the literal north_star bar at the real shapes — plus a handful of LoRA / norm / embedding gradients;
+  3. the attention kernels alone against an fp64 evaluation (causal + indirect rows, head widths 112 and 128, forward and backward).
+
+Full depth (32 + 63 layers) in this mode: tests/test_fulldepth_gpu.py."""
+import json
+import math
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+from tests._gpu_common import cpu, oracle_cfg, oracle_state, randomize_, rel
+
+pytestmark = pytest.mark.gpu
+REPORT: dict = {}
+BAR = 1e-3          # BASELINE.json north_star: "logits within 1e-3 rel of reference"
+
+
+def _oracle(m, batch, need_grad=False):
+    from oracle import vividmed as O
+    sd = oracle_state(m)
+    if need_grad:
+        sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    vi = cpu(batch['vlm_inputs'])
+    out = O.causal_lm_forward(sd, oracle_cfg(m.config), vi['input_ids'], image=[x.float() for x in cpu(batch['image'])],
+                              patch_size=batch['patch_size'], pool_size=batch['pool_size'], token_type_ids=vi['token_type_ids'],
+                              attention_mask=vi['attention_mask'], position_ids=vi['position_ids'], labels=vi['labels'],
+                              weight=vi['weight'].float(), rope_dtype=torch.float32)
+    return out, sd
+
+
+def _f32_images(batch):
+    return [x.float() for x in batch['image']]
+
+
+def test_attention_f32_causal_indirect_rows_vs_fp64(dev):
+    """vm_attn_fwd/bwd_f32 with `causal` + `row_of_pos` at head widths 112 (non-causal, ViT-E) and 128 (causal, decoder), two ragged
+    sequences scattered over a larger row buffer, against fp64 softmax attention"""
+    from mmmm_amd import functional as Fh
+    g = torch.Generator().manual_seed(5)
+    for hd, H, causal, lens in ((128, 4, True, (117, 201)), (112, 3, False, (197, 65)), (128, 2, True, (33, 1)), (64, 2, True, (40, 129))):
+        C = H * hd
+        T = sum(lens)
+        R = T + 11                                         # rows that belong to no sequence sit in between
+        perm = torch.randperm(R, generator=g)[:T].to(torch.int32)
+        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+        qkv = (0.5 * torch.randn(R, 3 * C, generator=g)).to(dev).requires_grad_(True)
+        dout = torch.randn(R, C, generator=g).to(dev)
+        out = Fh.self_attention_f32(qkv, H, hd, hd ** -0.5, cu.to(dev), max(lens), 1, causal, perm.to(dev))
+        out.backward(dout)
+        # fp64 on the host, sequence by sequence, in position order
+        q64 = qkv.detach().double().cpu().requires_grad_(True)
+        ref = torch.zeros(R, C, dtype=torch.float64)
+        for b in range(len(lens)):
+            rows = perm[cu[b]:cu[b + 1]].long()
+            x = q64[rows].view(-1, 3, H, hd)
+            q, k, v = (x[:, i].transpose(0, 1) for i in range(3))
+            s = q @ k.transpose(1, 2) * hd ** -0.5
+            if causal:
+                s = s.masked_fill(torch.ones(s.shape[-2:], dtype=torch.bool).triu(1), float('-inf'))
+            ref = ref.index_put((rows,), (s.softmax(-1) @ v).transpose(0, 1).reshape(-1, C))
+        ref.backward(dout.double().cpu())
+        used = perm.long()
+        e_o, e_g = rel(out[used.to(dev)], ref.detach()[used]), rel(qkv.grad[used.to(dev)], q64.grad[used])
+        REPORT[f'attention f32 hd {hd} causal {causal} lens {lens}'] = dict(out=e_o, dqkv=e_g)
+        assert e_o < 2e-6 and e_g < 5e-6, (hd, causal, e_o, e_g)
+        unused = torch.ones(R, dtype=torch.bool)
+        unused[used] = False
+        assert float(qkv.grad[unused.to(dev)].abs().max()) == 0.0 and float(out[unused.to(dev)].abs().max()) == 0.0
+
+
+@pytest.fixture(scope='module')
+def lm32(dev):
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, VisionArgs
+    from mmmm_amd.utils import apply_lora
+    from tests.test_model_gpu import tiny_config
+    m = MMMMForCausalLM(tiny_config(), vision_override=VisionArgs(pos_embed_shape=(2, 2, 4), patch_size=(4, 8, 8)))
+    apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    randomize_(m, 321)
+    m.to(dev)
+    assert all(p.dtype == torch.float32 for p in m.parameters())
+    return m
+
+
+def test_tiny_model_f32_forward_and_backward_vs_oracle(dev, lm32):
+    from tests.test_model_gpu import make_inputs
+    m = lm32
+    m.train()
+    batch, _ = make_inputs(dev, seed=5)
+    for p in m.parameters():
+        p.grad = None
+    out = m(**batch['vlm_inputs'], image=_f32_images(batch), patch_size=batch['patch_size'], pool_size=batch['pool_size'],
+            output_hidden_states=True, materialize_logits=True)
+    assert out.logits.dtype == torch.float32 and out.hidden_states[1].dtype == torch.float32
+    out.loss.backward()
+    ref, sd = _oracle(m, batch, need_grad=True)
+    ref.loss.backward()
+    am = cpu(batch['vlm_inputs']['attention_mask']).bool()
+    r = dict(loss=abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()), logits=rel(out.logits.cpu()[am], ref.logits.detach()[am]),
+             hidden=max(rel(out.hidden_states[i].cpu()[am], ref.hidden_states[i].detach()[am]) for i in range(len(ref.hidden_states))))
+    grads = {}
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None and sd[n].grad is not None, n
+        grads[n] = rel(p.grad, sd[n].grad)
+    r['gradients (worst of %d)' % len(grads)] = max(grads.values())
+    r['worst gradient'] = max(grads, key=grads.get)
+    REPORT['tiny model, fp32 towers'] = r
+    assert len(grads) > 40
+    assert r['loss'] < BAR and r['logits'] < BAR and r['hidden'] < BAR, r
+    assert max(grads.values()) < BAR, sorted(grads.items(), key=lambda kv: -kv[1])[:5]
+    # the arithmetic is fp32, not "bf16 that happens to pass": two orders below the bar
+    assert r['logits'] < 2e-5 and r['hidden'] < 2e-5, r
+
+
+WATCH = (
+    'model.layers.0.self_attn.vision_expert_query_key_value.lora_A.default.weight',
+    'model.layers.1.self_attn.language_expert_dense.lora_B.default.weight',
+    'model.layers.1.mlp.vision_mlp.down_proj.lora_A.default.weight',
+    'model.layers.1.mlp.language_mlp.up_proj.lora_B.default.weight',
+    'model.layers.1.post_attention_layernorm.weight',
+    'model.norm.weight',
+    'model.embed_tokens.weight',
+    'lm_head.weight',
+    'model.vision.transformer.layers.0.attention.query_key_value.lora_A.default.weight',
+    'model.vision.transformer.layers.1.mlp.fc2.lora_A.default.weight',
+    'model.vision.linear_proj.dense_h_to_4h.lora_B.default.weight',
+)
+
+
+def test_config0_true_width_f32_logits_within_1e3(dev):
+    """BASELINE configs[0] (1 x 224 x 224, batch 1, L = 117, Nv = 197) at the true widths, 2 + 2 layers, fp32 towers: the literal bar"""
+    from mmmm_amd.data.synthetic import SpecialTokens, make_batch
+    from mmmm_amd.models.cogvlm.configuration_cogvlm import CogVLMConfig
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, VisionArgs
+    from mmmm_amd.utils import apply_lora
+    from tests.test_config0_gpu import _randomize_on_device_
+    cfg = CogVLMConfig(num_hidden_layers=2)
+    cfg.vision_config['num_hidden_layers'] = 2
+    tok = SpecialTokens(base_vocab=32000)
+    with torch.device(dev):
+        m = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(8, 32, 32), pt_pos_embed_shape=(35, 35), patch_size=16),
+                                  tokenizer=tok, config=cfg)
+    apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    _randomize_on_device_(m, 2240)
+    assert m.lm_head.weight.dtype == torch.float32 and m.config.hidden_size == 4096 and m.config.vocab_size == 32008
+    m.train()
+    batch = make_batch([(3, 1, 224, 224)], [(1, 16, 16)], [(1, 2, 2)], [64], tok=tok, seed=224, grounding=True, n_pairs=3, device=dev)
+    vi = batch['vlm_inputs']
+    assert vi['input_ids'].shape == (1, 117)
+    out = m(**vi, image=_f32_images(batch), patch_size=batch['patch_size'], pool_size=batch['pool_size'], output_hidden_states=True,
+            materialize_logits=True)
+    out.loss.backward()
+    # one oracle pass; gradients of the watched tensors only (autograd over 3.5 B fp32 parameters is what would take the time)
+    from oracle import vividmed as O
+    sdw = {k: (v.requires_grad_(True) if k in WATCH else v) for k, v in oracle_state(m).items()}
+    cv = cpu(vi)
+    ref = O.causal_lm_forward(sdw, oracle_cfg(m.config), cv['input_ids'], image=[x.float() for x in cpu(batch['image'])],
+                              patch_size=batch['patch_size'], pool_size=batch['pool_size'], token_type_ids=cv['token_type_ids'],
+                              attention_mask=cv['attention_mask'], position_ids=cv['position_ids'], labels=cv['labels'],
+                              weight=cv['weight'].float(), rope_dtype=torch.float32)
+    ref.loss.backward()
+    ref.logits, ref.hidden_states = ref.logits.detach(), [h.detach() for h in ref.hidden_states]
+    am = cpu(vi['attention_mask']).bool()
+    r = dict(loss=abs(out.loss.item() - ref.loss.item()) / abs(ref.loss.item()), logits=rel(out.logits.cpu()[am], ref.logits[am]),
+             last_hidden=rel(out.hidden_states[-1].cpu()[am], ref.hidden_states[-1][am]),
+             hidden_0=rel(out.hidden_states[0].cpu()[am], ref.hidden_states[0][am]))
+    ps = dict(m.named_parameters())
+    grads = {n: rel(ps[n].grad, sdw[n].grad) for n in WATCH}
+    r['gradients'] = grads
+    REPORT['configs[0] true width 2 + 2 layers, fp32 towers'] = r
+    assert r['logits'] < BAR and r['last_hidden'] < BAR and r['loss'] < BAR and r['hidden_0'] < BAR, r
+    assert max(grads.values()) < BAR, grads
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_zz_report():
+    print('\n' + json.dumps(REPORT, indent=1))
+    out = Path(os.environ.get('GRAFT_REPO_ROOT', Path(__file__).resolve().parents[1])) / 'gpurun_out'
+    if out.is_dir() and REPORT:
+        (out / 'r6_parity_f32_towers.json').write_text(json.dumps(REPORT, indent=1))

@@ -1,0 +1,176 @@
+"""BASELINE.json configs[0] at FULL DEPTH, forward: one 1x224x224 2-D image (Nv = 197 ViT tokens, Np = 49 image tokens, T = 64 text
+tokens, L = 117), batch 1, CogVLM at its real 32 decoder layers (4096 / 11008 / 32 heads of 128, both experts) + EVA-ViT-E at its real 63
+layers (1792 / 15360 / 16 heads of 112) + GLU adapter, vocabulary 32 008, LoRA r64 on every linear: 17.6 B base parameters.
+
+The loops under test are the ones no earlier round compared at their real trip count: the decoder stack `modeling_cogvlm.py:547-562`
+(inside `CogVLMForCausalLM.forward` :659-715) and the ViT stack `visual.py:151-159`. tests/test_config0_gpu.py stops at 2 + 2 layers
+(8 decoder layers in its sweep) and EXTRAPOLATES the 32-layer error with a power law; this test MEASURES it:
+
+    HIP bf16 (the product)  vs  the oracle in fp32  vs  the oracle in bf16-true, both evaluated on the GPU box's host cores
+
+on the same weights (generated on the device in bf16, copied to the host ONCE: 35 GB; the fp32 oracle reads them through a dict that
+widens a tensor when it is asked for it — bf16 -> fp32 is exact, so this IS the fp32 evaluation of the same model, and the host never
+holds the 70 GB fp32 copy). Compared: the logits on the valid rows, the last hidden state, the weighted CE loss, and the hidden state in
+front of decoder layers 0 (= embedding + what the 63-layer tower produced), 8, 16, 24. The assertion is the evidence-based bf16 rule of
+tests/test_truewidth_gpu.py: |hip - fp32| <= 1.3 e_ref, |hip - bf16| <= 1.5 e_ref with e_ref = the oracle's own bf16-vs-fp32 gap (plus
+1e-4). No bf16-true evaluation, the reference's own included, reaches north_star's literal "1e-3 rel" at this depth (measured here: the
+oracle's bf16-true logits are 0.28 away from its fp32 logits on these random weights — 63 + 32 layers amplify the bf16 rounding of
+every layer), so the same model is then widened to fp32 ON THE DEVICE and run through the towers' fp32 mode (tests/test_f32_towers_gpu.py):
+that run must agree with the fp32 oracle to 1e-3 on logits, last hidden state and loss. Everything goes to gpurun_out/r6_parity_fulldepth.json.
+
+Skipped when the host has less than 56 GB of free memory (35 GB of weights + working set)."""
+import json
+import os
+import time
+from pathlib import Path
+
+import pytest
+import torch
+
+from tests._gpu_common import cpu, oracle_cfg, rel
+from tests.test_config0_gpu import _randomize_on_device_
+
+pytestmark = pytest.mark.gpu
+NEED_HOST_GB = 56
+
+
+class WideningState(dict):
+    """bf16 host state dict that hands out fp32 tensors (exact widening, one tensor at a time)"""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return v.float() if v.is_floating_point() else v
+
+
+def _host_free_gb() -> float:
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:       # pragma: no cover
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable'):
+                    return int(line.split()[1]) / 2 ** 20
+    return 0.0
+
+
+def test_config0_full_depth_forward_vs_oracle(dev):
+    free = _host_free_gb()
+    if free < NEED_HOST_GB:
+        pytest.skip(f'host has {free:.0f} GB free, the full-depth oracle needs {NEED_HOST_GB}')
+    from oracle import vividmed as O
+    from mmmm_amd.data.synthetic import SpecialTokens, make_batch
+    from mmmm_amd.models.cogvlm.configuration_cogvlm import CogVLMConfig
+    from mmmm_amd.models.lora import LoraConfig
+    from mmmm_amd.models.mmmm import MMMMForCausalLM, VisionArgs
+    from mmmm_amd.utils import apply_lora
+    t0 = time.time()
+    cfg = CogVLMConfig()
+    assert cfg.num_hidden_layers == 32 and cfg.vision_config['num_hidden_layers'] == 63
+    tok = SpecialTokens(base_vocab=32000)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            m = MMMMForCausalLM.build(None, vision_override=VisionArgs(pos_embed_shape=(8, 32, 32), pt_pos_embed_shape=(35, 35), patch_size=16),
+                                      tokenizer=tok, config=cfg)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    apply_lora(m, LoraConfig(r=64, lora_alpha=8, lora_dropout=0.0, use_rslora=True))
+    _randomize_on_device_(m, 632)
+    m.to(torch.bfloat16).eval()
+    n_base = sum(p.numel() for n, p in m.named_parameters() if 'lora_' not in n)
+    assert n_base > 17.0e9, n_base
+    batch = make_batch([(3, 1, 224, 224)], [(1, 16, 16)], [(1, 2, 2)], [64], tok=tok, seed=7, grounding=True, n_pairs=3, device=dev)
+    vi = batch['vlm_inputs']
+    assert vi['input_ids'].shape == (1, 117) and int(vi['token_type_ids'].sum()) == 51
+    am = cpu(vi['attention_mask']).bool()
+    assert (vi['weight'] == 5).any() and (vi['labels'] >= 0).sum() == 64          # <p> targets weigh 5 (conf data.yaml:101)
+    t_build = time.time() - t0
+    # ---- the product: one forward through libvividmed_hip.so
+    t0 = time.time()
+    with torch.no_grad():
+        out = m(**vi, image=batch['image'], patch_size=batch['patch_size'], pool_size=batch['pool_size'], return_dict=True,
+                output_hidden_states=True, materialize_logits=True)       # vi carries labels + weight: loss and logits in one pass
+        loss_hip = out.loss
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    assert len(out.hidden_states) == 33 and out.logits.shape == (1, 117, 32008)
+    hip = dict(logits=out.logits.float().cpu(), hidden={k: out.hidden_states[k].float().cpu() for k in (0, 8, 16, 24, 32)}, loss=float(loss_hip))
+    # ---- the weights, once, to the host (bf16)
+    t0 = time.time()
+    sd16 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert all(v.dtype == torch.bfloat16 for v in sd16.values() if v.is_floating_point())
+    t_copy = time.time() - t0
+    ocfg = oracle_cfg(m.config)
+    cv = cpu(vi)
+    img = cpu(batch['image'])
+    res, secs = {}, {}
+    for mode, sd, dt in (('fp32', WideningState(sd16), torch.float32), ('bf16', sd16, torch.bfloat16)):
+        t0 = time.time()
+        with torch.no_grad():
+            o = O.causal_lm_forward(sd, ocfg, cv['input_ids'], image=[x.to(dt) for x in img], patch_size=batch['patch_size'],
+                                    pool_size=batch['pool_size'], token_type_ids=cv['token_type_ids'], attention_mask=cv['attention_mask'],
+                                    position_ids=cv['position_ids'], labels=cv['labels'],
+                                    weight=cv['weight'].to(dt) if cv.get('weight') is not None else None, rope_dtype=torch.bfloat16)
+        secs[mode] = time.time() - t0
+        assert o.logits.dtype == torch.float32 and o.hidden_states[-1].dtype == dt and len(o.hidden_states) == 33
+        res[mode] = dict(logits=o.logits, hidden={k: o.hidden_states[k].float() for k in (0, 8, 16, 24, 32)}, loss=float(o.loss))
+    r32, r16 = res['fp32'], res['bf16']
+    report = {'config': 'BASELINE configs[0]: 1x224x224, batch 1, L = 117, Nv = 197; 32 decoder + 63 ViT layers at true width, forward',
+              'base_parameters': n_base, 'host_threads': torch.get_num_threads(),
+              'seconds': dict(build_and_randomize=t_build, hip_forward_incl_first_call_setup=t_hip, weights_to_host=t_copy,
+                              oracle_fp32=secs['fp32'], oracle_bf16=secs['bf16'])}
+
+    def row(what, got, a16, a32):
+        r = dict(e_ref=rel(a16, a32), e_hip=rel(got, a32), hip_vs_oracle_bf16=rel(got, a16))
+        report[what] = r
+        return r
+    rows = [row('logits (valid rows)', hip['logits'][am], r16['logits'][am], r32['logits'][am])]
+    for k in (32, 24, 16, 8, 0):
+        name = {32: 'last hidden state (after the final norm)', 0: 'hidden state 0 (embedding + the 63-layer tower\'s image tokens)'}.get(
+            k, f'hidden state in front of decoder layer {k}')
+        rows.append(row(name, hip['hidden'][k][am], r16['hidden'][k][am], r32['hidden'][k][am]))
+    report['loss'] = dict(hip=hip['loss'], fp32=r32['loss'], bf16=r16['loss'],
+                          e_ref=abs(r16['loss'] - r32['loss']) / abs(r32['loss']), e_hip=abs(hip['loss'] - r32['loss']) / abs(r32['loss']))
+    # top-1 agreement on the valid rows: what a 4e-2 relative logits error does to the prediction
+    t32 = r32['logits'][am].argmax(-1)
+    report['top1 agreement with the fp32 oracle'] = dict(hip=float((hip['logits'][am].argmax(-1) == t32).float().mean()),
+                                                         oracle_bf16=float((r16['logits'][am].argmax(-1) == t32).float().mean()))
+    # ---- the towers' fp32 mode at full depth: north_star's literal bar. The same model widened to fp32 on the device (exact: its values are
+    # bf16 numbers; the rotary tables stay the bf16 model's, as in the oracle's fp32 run above), every linear / norm / attention on the fp32
+    # entry points (tests/test_f32_towers_gpu.py), against that oracle run: |hip32 - oracle32| on logits, last hidden state, loss.
+    from mmmm_amd.models.cogvlm.modeling_cogvlm import RotaryEmbedding
+    del out
+    m.float()
+    for mod in m.modules():
+        if isinstance(mod, RotaryEmbedding):
+            mod.inv_freq = mod.inv_freq.bfloat16()
+            mod._cache = None
+    torch.cuda.empty_cache()
+    assert m.lm_head.weight.dtype == torch.float32
+    t0 = time.time()
+    with torch.no_grad():
+        out32 = m(**vi, image=[x.float() for x in batch['image']], patch_size=batch['patch_size'], pool_size=batch['pool_size'],
+                  return_dict=True, output_hidden_states=True, materialize_logits=True)
+    torch.cuda.synchronize()
+    report['seconds']['hip_fp32_forward'] = time.time() - t0
+    f32 = dict(logits=rel(out32.logits.cpu()[am], r32['logits'][am]),
+               last_hidden=rel(out32.hidden_states[32].cpu()[am], r32['hidden'][32][am]),
+               hidden_0=rel(out32.hidden_states[0].cpu()[am], r32['hidden'][0][am]),
+               loss=abs(float(out32.loss) - r32['loss']) / abs(r32['loss']),
+               top1_agreement=float((out32.logits.cpu()[am].argmax(-1) == t32).float().mean()))
+    report['fp32 towers (vm_gemm_f32 / vm_attn_f32 ...) vs the fp32 oracle: relative error'] = f32
+    print('\n' + json.dumps(report, indent=1))
+    outdir = Path(os.environ.get('GRAFT_REPO_ROOT', Path(__file__).resolve().parents[1])) / 'gpurun_out'
+    if outdir.is_dir():
+        (outdir / 'r6_parity_fulldepth.json').write_text(json.dumps(report, indent=1))
+    for r in rows:
+        assert r['e_hip'] <= 1.3 * r['e_ref'] + 1e-4 and r['hip_vs_oracle_bf16'] <= 1.5 * r['e_ref'] + 1e-4, (r, report)
+    # one number, not a norm over many: the absolute floor of test_config0's scalars
+    assert abs(hip['loss'] - r32['loss']) <= (3 * report['loss']['e_ref'] + 5e-3) * abs(r32['loss']), report['loss']
+    # BASELINE.json north_star: "logits within 1e-3 rel of reference" — at the real depth, in the reference's own precision for this config
+    assert f32['logits'] <= 1e-3 and f32['last_hidden'] <= 1e-3 and f32['loss'] <= 1e-3 and f32['hidden_0'] <= 1e-3, f32
+    del m, sd16
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
