@@ -281,7 +281,7 @@ def run_also(workloads: list, args) -> list:
     t_all = time.perf_counter()
     for spec in workloads:
         wl, _, mode = spec.partition(':')
-        if wl not in WORKLOADS or mode not in ('', 'fp8'):
+        if wl not in WORKLOADS or mode not in ('', 'fp8', 'exact-islands'):
             raise SystemExit(f'--also: unknown workload {spec}')
         if time.perf_counter() - t_all > args.also_budget:
             out.append({'workload': spec, 'skipped': f'--also-budget {args.also_budget:.0f} s used up by the workloads before it'})
@@ -290,6 +290,10 @@ def run_also(workloads: list, args) -> list:
         cmd = [sys.executable, str(Path(__file__).resolve()), '--workload', wl, '--steps', '12', '--warmup', '3', '--no-cpu-baseline',
                '--no-kernel-events', '--no-peak-probe', '--also', '', '--batch', str(batch), '--checkpointing', args.checkpointing,
                '--hbm-fraction', str(args.hbm_fraction)] + (['--fp8'] if mode == 'fp8' else [])
+        if mode == 'exact-islands':
+            # the fp32 islands entirely on six-product (fp32-exact) arithmetic: the step time the three-product default of the two SAM-B
+            # image encoders (config.fp32_islands) is traded against
+            cmd += ['--set', 'models.segvol.modeling.image_encoder.ENCODER_F32_SPLIT=3']
         t0 = time.perf_counter()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         line = next((ln for ln in r.stdout.splitlines() if ln.startswith('{')), None)
@@ -386,9 +390,12 @@ def apply_sets(sets) -> bool:
         parts = path.split('.')
         m, k = None, len(parts) - 1
         while k > 0 and m is None:                 # the longest importable module prefix, then attributes (a class constant: models.mmmm.MMMMForCausalLM.concurrent_heads)
+            name_k = 'mmmm_amd.' + '.'.join(parts[:k])
             try:
-                m = importlib.import_module('mmmm_amd.' + '.'.join(parts[:k]))
-            except ImportError:
+                m = importlib.import_module(name_k)
+            except ModuleNotFoundError as e:       # only "this prefix is not a module": a failing import INSIDE a module is an error of its own
+                if e.name is None or not name_k.startswith(e.name):
+                    raise
                 k -= 1
         if m is None:
             raise SystemExit(f'--set {item}: no module behind mmmm_amd.{path}')
@@ -441,7 +448,10 @@ def main():
     ap.add_argument('--no-peak-probe', action='store_true', help='skip the 2 s MFMA peak measurement (roofline.peak_measured)')
     ap.add_argument('--also-budget', type=float, default=330.0,
                     help='seconds of wall clock for the --also children together: a child is only started while the budget lasts (the rest are reported as skipped)')
-    ap.add_argument('--also', default='phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8,model-hr-3d',
+    ap.add_argument('--cpu-baseline-budget', type=float, default=100.0,
+                    help="seconds of host time for the CPU baselines of the --also workloads (oracle training_step of ONE image at the true widths, 1 + 1 and "
+                         "2 + 2 layers, depth extrapolated — the headline's method); a workload is only timed while the budget lasts")
+    ap.add_argument('--also', default='phase-vlm-448,phase-vlm-mixed,phase-grg-3d,model-hr-2d,model-hr-2d:fp8,model-hr-3d,phase-vg-448:exact-islands',
                     help="N = 1 only: further workloads measured by child processes BEFORE the headline run (12 timed steps each) and "
                          "reported under 'also' in the same JSON line — the north_star's target is quoted on phase-vlm; '' disables")
     ap.add_argument('--set', action='append', default=[], metavar='MODULE.NAME=VALUE',
@@ -655,7 +665,8 @@ def main():
             'vs_baseline': None, 'dtype': 'fp8-e4m3 frozen-weight GEMMs (fwd + dgrad), bf16 elsewhere' if args.fp8 else 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'description': w['desc'], 'per_gpu_batch': args.batch, 'global_batch': args.batch * world,
                        'text_tokens': w['text'], 'distinct_batches': len(batches), 'parallelism': f'dp{world}', 'weights': 'random-init', 'lora': 'r64 rsLoRA dropout 0.05', 'sam': 'SAM-B + iSAM fp32, unfrozen (README Stage 1: --model.freeze_sam false --model.freeze_isam false)' if w['sam'] else None,
-                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (image_encoder.ENCODER_F32_SPLIT = %d)' % _enc_split()) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale},
+                       'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (image_encoder.ENCODER_F32_SPLIT = %d)' % _enc_split()) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale,
+                       'resample': 'parity UNPINNED for one op on this path: luolib.models.spadop.resample (the position tables [C, 8, 32, 32] -> the image\'s patch grid, every step; visual.py:44-66, image_encoder.py:74-115) lives in an un-vendored submodule absent from /root/reference — mmmm_amd/models/resample.py and the oracle restate it as linear interpolation (align_corners False), and no test can see that guess being wrong'},
             'loss': loss_v,
             'host_enqueue_ms': min(host_enq),
             'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min of 2 untimed steps after the timed region); must stay below ms_per_step',
@@ -707,6 +718,24 @@ def main():
             out['also'] = also
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(w, model.config, tok)
+            # the other workloads' CPU baselines by the same method (reduced depth x depth ratio), one per distinct workload,
+            # while --cpu-baseline-budget lasts; a mixed batch is half 2-D, half 3-D images: the mean time per image of the two shapes
+            t_cb, done = time.perf_counter(), {args.workload: out['cpu_baseline']}
+            for a in also:
+                wl = a['workload'].partition(':')[0]
+                if 'value' not in a:
+                    continue
+                if wl not in done:
+                    if time.perf_counter() - t_cb > args.cpu_baseline_budget:
+                        done[wl] = {'skipped': f'--cpu-baseline-budget {args.cpu_baseline_budget:.0f} s used up by the workloads before it'}
+                    elif WORKLOADS[wl].get('mixed'):
+                        parts = [done['phase-vlm-448'] if 'value' in done.get('phase-vlm-448', {}) else cpu_baseline(WORKLOADS['phase-vlm-448'], model.config, tok),
+                                 cpu_baseline(dict(WORKLOADS['phase-grg-3d'], sam=False), model.config, tok)]
+                        done[wl] = {'value': 2.0 / sum(1.0 / q['value'] for q in parts), 'unit': 'images/s', 'cores': parts[0]['cores'], 'kind': 'port',
+                                    'sample': 'half 2-D 448x448, half 3-D 32x256x256 images (text 256): mean time per image of [' + ' | '.join(q['sample'] for q in parts) + ']'}
+                    else:
+                        done[wl] = cpu_baseline(WORKLOADS[wl], model.config, tok)
+                a['cpu_baseline'] = done[wl]
         print(json.dumps(out), file=reserve_stdout(), flush=True)
     if use_dist:
         dist.destroy_process_group()

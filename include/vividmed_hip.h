@@ -44,7 +44,7 @@ extern "C" {
 #define VM_ACT_RELU 2
 
 /* library / device info --------------------------------------------------- */
-int vm_version(void);   /* 510 = VM_TN_GROUP_MAX 24 -> 32; 500 = round 5 (vm_gemm_args grew by workspace / workspace_bytes; vm_gemm_workspace_bytes added; vm_lora_down_fused removed), 400 = round 4
+int vm_version(void);   /* 600 = round 6 (vm_attn_f32_args grew by causal / row_of_pos; head width 112); 510 = VM_TN_GROUP_MAX 24 -> 32; 500 = round 5 (vm_gemm_args grew by workspace / workspace_bytes; vm_gemm_workspace_bytes added; vm_lora_down_fused removed), 400 = round 4
                           * (vm_attn_args grew by workspace / workspace_bytes). The argument structs below only ever GROW at their end; a caller built against an older
                           * header must be rebuilt when this number changes (there is no struct_size field). */
 /* fills name[0..len) with the gcnArchName of the current device */
@@ -142,7 +142,13 @@ typedef struct vm_gemm_args {
                                                 says a partial round would otherwise be paid (e.g. 288 tiles over 256 CUs); results then differ from the
                                                 one-tile-per-workgroup kernel by the fp32 rounding of ONE extra addition per element of a split tile, and are
                                                 bit-identical from launch to launch (the split points and the summation order are functions of the shape and
-                                                of the device-side row counts only). NULL: every tile is computed by one workgroup, as before round 5. */
+                                                of the device-side row counts only). NULL: every tile is computed by one workgroup, as before round 5.
+                                                AS SHIPPED the cost model never picks that form (it measured slower on every shape of the six workloads: DESIGN.md
+                                                section 3), so passing a workspace changes nothing unless the internal switch vm_gemm_sched_mode_(1 | 2) was set —
+                                                which only the tests and tools/ubench/gemm_bench do. Under that switch an owner workgroup that gives up waiting for a
+                                                contributor's slab (a bounded spin: it cannot happen while all `multiProcessorCount` workgroups are co-resident, i.e.
+                                                while nothing else occupies CUs of the device) marks word `workers` of the flag area behind the slabs; the tests read
+                                                it, the library does not: the form is a measured experiment, not a supported mode. */
 } vm_gemm_args;
 
 int vm_gemm_bf16(const vm_gemm_args* args_host, void* stream);

@@ -502,7 +502,7 @@ extern "C" int vm_prof_end2_(int kind, void* stream, void* tok, double flops, do
 
 extern "C" {
 
-int vm_version(void) { return 510; }      /* 510: VM_TN_GROUP_MAX 24 -> 32 (vm_tn_skinny_group_bf16 takes up to 32 items); 500: round 5 (vm_gemm_args.workspace / workspace_bytes, vm_gemm_workspace_bytes); 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
+int vm_version(void) { return 600; }      /* 600: round 6 (vm_attn_f32_args.causal / row_of_pos, head width 112); 510: VM_TN_GROUP_MAX 24 -> 32 (vm_tn_skinny_group_bf16 takes up to 32 items); 500: round 5 (vm_gemm_args.workspace / workspace_bytes, vm_gemm_workspace_bytes); 400: round 4 (vm_attn_args.workspace / workspace_bytes); 300: round 3 (vm_gemm_args.b_nn / f32_split, vm_attn_f32_args.f32_split) */
 
 int vm_device_arch(char* name_host, int len) {
   int dev = 0;
@@ -710,8 +710,10 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   void* tok = nullptr;
   vm_prof_begin_(kind, stream, &tok);
   const bool sk_ok = esz == 2 && !a->b_nn && a->workspace && a->workspace_bytes >= vm_gemm256sk_workspace_(cu_count());
-  SkPlan plan = (esz == 2 && p.ksplit <= 1) ? sched_plan(a->M, a->N, (a->K + a->K2) / 64, SK_T_K_BF16, segmented, sk_ok) : SkPlan{0, 0};
-  if (plan.kind == 3 && (a->b_nn || a->out_dtype != VM_BF16)) plan = SkPlan{1, 192};      // (the tails launch is the bf16 128 x 128 kernel)
+  // (the tails launch is the bf16-output 128 x 32 kernel on an NT weight: other calls are planned WITHOUT plan 3, so that they get the best of
+  // the remaining plans — 256-row, 192-row or 128 x 128 tiles — instead of a fixed fallback)
+  const bool tails_legal = !a->b_nn && a->out_dtype == VM_BF16;
+  SkPlan plan = (esz == 2 && p.ksplit <= 1) ? sched_plan(a->M, a->N, (a->K + a->K2) / 64, SK_T_K_BF16, segmented, sk_ok, tails_legal) : SkPlan{0, 0};
   int big = plan.kind ? plan.rows : 0;
   if (a->b_nn) {
     // weight given as [K, N] (contraction-major, e.g. W itself for dx = dy W): only the 256-column kernel has that operand path
@@ -769,7 +771,8 @@ static int gemm_launch(const vm_gemm_args* a, void* stream, int esz) {
   return VM_OK;
 }
 
-/* internal (tests, tools): what the scheduler would run for a bf16 shape — kind 0 = 128 x 128 tiles, 1 = one 256-column tile per workgroup, 2 = stream-K */
+/* internal (tests, tools): what the scheduler would run for a bf16-output NT shape — kind 0 = 128 x 128 tiles, 1 = one 256-column tile per workgroup
+ * (`rows` 256 or 192), 2 = stream-K (only with a workspace AND vm_gemm_sched_mode_ > 0), 3 = full 256-row tiles + a tails launch (vm_gemm_tails_mode_) */
 int vm_gemm_plan_(int M, int N, int K, int K2, int segmented, int with_workspace, int* kind_host, int* rows_host) {
   const SkPlan pl = sched_plan(M, N, (K + K2) / 64, SK_T_K_BF16, segmented != 0, with_workspace != 0);
   if (kind_host) *kind_host = pl.kind;

@@ -125,7 +125,11 @@ __device__ __forceinline__ VmHash4 vm_hash4w(const VmSeed& s, unsigned group) {
 }
 __device__ __forceinline__ bool vm_fits32(int64_t rows, int64_t cols) { return rows * cols < (1ll << 34); }
 // The drop threshold is EVEN (p = 0.05: 3276 / 65536, unchanged): "field >= thr" is then "field >> 1 >= thr >> 1" on 15-bit values, which
-// the packed 16-bit instructions decide for two elements at once (vm_mask8w below).
+// the packed 16-bit instructions decide for two elements at once (vm_mask8w below). Consequence of clearing bit 0: for a p whose
+// floor(p * 65536) is odd the realised drop rate is 1 / 65536 below p while the fused 1 / (1 - p) scale uses p itself — a relative bias of
+// 1.5e-5 / (1 - p) on the LoRA branch, far below the bf16 rounding of the branch's input; torch's own dropout realises p to 2^-24.
+// The 32-bit group index of vm_hash4w (element index / 4) requires a row pitch that is a multiple of 4 elements: callers check `cols % 4 == 0`
+// next to vm_fits32 (lora_down_k, tn_group_k) and take the 64-bit vm_hash4 form otherwise.
 __device__ __forceinline__ unsigned vm_drop_threshold(float p) { return (unsigned)(p * 65536.0f) & ~1u; }
 __device__ __forceinline__ bool vm_keep_bits(uint64_t h, int sub, unsigned thr) {
   return ((unsigned)(h >> (16 * sub)) & 0xFFFFu) >= thr;

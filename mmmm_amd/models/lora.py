@@ -132,7 +132,10 @@ class Linear(nn.Module):
         b = torch.zeros(self.out_features, cfg.r, dtype=w.dtype, device=w.device)
         self.lora_A = nn.ModuleDict({'default': _Holder(a)})
         self.lora_B = nn.ModuleDict({'default': _Holder(b)})
-        self.__dict__.pop('_A', None), self.__dict__.pop('_B', None)
+        self._drop_factor_cache()
+        if not getattr(self, '_factor_hook', False):
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_factor_cache())
+            self._factor_hook = True
         self.lora_cfg = cfg
         self.weight.requires_grad_(False)
         if self.bias is not None:
@@ -156,6 +159,19 @@ class Linear(nn.Module):
             b = self.lora_B['default'].weight
             self.__dict__['_B'] = b
         return b
+
+    def _drop_factor_cache(self):
+        self.__dict__.pop('_A', None), self.__dict__.pop('_B', None)
+
+    # Everything that can REPLACE the Parameter objects (rather than write into them) goes through one of these two: `_apply` (to / to_empty /
+    # cuda / float / ... incl. the swap-module-params-on-conversion switches) and `load_state_dict(assign=True)` (-> _load_from_state_dict of the
+    # holder, whose parent gets the post hook below). The cached objects are dropped there, so forward and the factor-gradient queue can never
+    # keep using tensors the module no longer owns.
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_factor_cache()
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_factor_cache()
+        return out
 
     def fp8_eligible(self) -> bool:
         w = self.weight

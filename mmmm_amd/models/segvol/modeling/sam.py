@@ -134,6 +134,9 @@ def box_pair_giou(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
 
 
 class InstanceSamLoss(nn.Module):
+    fused = True        # False: element-wise torch form on the GPU as well (a class constant like DiceFocalLoss.fused: tests set it per instance,
+                        # `bench.py --set models.segvol.modeling.sam.InstanceSamLoss.fused=False` for A/B runs)
+
     def __init__(self, *, mask_loss: DiceFocalLoss | None = None, use_neg_mask: bool, box_l1_weight: float, box_giou_weight: float,
                  disc_weight: float, disc_focal_gamma: float, disc_focal_alpha: float | None = None, match_ce: bool = True):
         super().__init__()
@@ -142,7 +145,6 @@ class InstanceSamLoss(nn.Module):
         self.box_l1_weight, self.box_giou_weight, self.disc_weight = box_l1_weight, box_giou_weight, disc_weight
         self.disc_focal_gamma, self.disc_focal_alpha = disc_focal_gamma, disc_focal_alpha
         self.match_ce = match_ce
-        self.fused = True      # 0: element-wise torch form on the GPU as well (A/B, tests)
 
     def box_loss(self, input, target, reduce_batch: bool = True, return_dict: bool = False):
         l1 = F.l1_loss(input, target) if reduce_batch else F.l1_loss(input, target, reduction='none').mean(dim=-1)

@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: LoRA target discovery vs the reference's lists (fixture F9), state-dict key
 parity of the grounding heads, synthetic batch layout vs prepare_vlm_inputs' rules, FLOP model vs SURVEY §8d."""
+from pathlib import Path
+
 import torch
 
 from tests import _tiny  # noqa: F401
@@ -94,3 +96,43 @@ def test_flop_model_matches_survey_table():
     assert abs(f - 28.59) < 0.02
     f = bench.train_flops_per_sample(bench.WORKLOADS['phase-grg-3d'], CogVLMConfig(), True) / 1e12
     assert abs(f - 59.60) < 0.02
+
+
+def test_lora_factor_cache_follows_replaced_parameters():
+    """`Linear.A` / `.B` cache the Parameter objects (the step reads them ~3 700 times); whatever REPLACES the parameters — load_state_dict(assign=True),
+    to_empty(), a dtype / device conversion — must drop the cache, or forward and the factor-gradient queue would keep using tensors the module no
+    longer owns (advisor, round 5)"""
+    from mmmm_amd.models.lora import Linear, LoraConfig
+    lin = Linear(8, 8)
+    lin.add_lora(LoraConfig(r=4))
+    a0, b0 = lin.A, lin.B
+    assert a0 is lin.lora_A['default'].weight and b0 is lin.lora_B['default'].weight
+    lin.load_state_dict({k: v.clone() + 1 for k, v in lin.state_dict().items()}, assign=True)
+    assert lin.A is lin.lora_A['default'].weight and lin.A is not a0 and lin.B is lin.lora_B['default'].weight and lin.B is not b0
+    lin.to(torch.float64)
+    assert lin.A is lin.lora_A['default'].weight and lin.A.dtype == torch.float64
+    _ = lin.A, lin.B
+    lin.to_empty(device='cpu')
+    assert lin.A is lin.lora_A['default'].weight and lin.B is lin.lora_B['default'].weight
+    # a plain in-place load keeps the objects (and the cache)
+    a1 = lin.A
+    lin.load_state_dict({k: torch.zeros_like(v) for k, v in lin.state_dict().items()})
+    assert lin.A is a1 and float(lin.A.detach().abs().sum()) == 0.0
+
+
+def test_bench_set_reports_a_broken_import_instead_of_hiding_it(tmp_path, monkeypatch):
+    """bench.apply_sets probes module prefixes: only 'this prefix is not a module' may be swallowed (advisor, round 5)"""
+    import bench
+    import pytest
+    bench.apply_sets(['models.segvol.modeling.sam.InstanceSamLoss.fused=True'])        # a class constant behind a module prefix
+    from mmmm_amd.models.segvol.modeling.sam import InstanceSamLoss
+    assert InstanceSamLoss.fused is True
+    with pytest.raises(SystemExit):
+        bench.apply_sets(['functional.NO_SUCH_CONSTANT=1'])
+    import mmmm_amd
+    (Path(mmmm_amd.__file__).parent / '_broken_probe.py').write_text('import a_module_that_does_not_exist_anywhere\n')
+    try:
+        with pytest.raises(ModuleNotFoundError):
+            bench.apply_sets(['_broken_probe.X=1'])
+    finally:
+        (Path(mmmm_amd.__file__).parent / '_broken_probe.py').unlink()
