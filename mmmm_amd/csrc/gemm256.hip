@@ -21,6 +21,9 @@
 
 namespace {
 
+#ifndef VM_GEMM_W4_DEFAULT
+#define VM_GEMM_W4_DEFAULT 0
+#endif
 constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
 constexpr int STAGE_BYTES2 = 4 * HALF_BYTES;
 constexpr int LDS_BYTES2 = 2 * STAGE_BYTES2;
@@ -440,6 +443,8 @@ __device__ __forceinline__ void gemm256_segment(const GemmParams& p, char* smem,
   epilogue256<OUT_F32, MI>(p, acc, smem, wave, lane, wm, wn, row0, nrows, n0, ncols, seg);
 }
 
+#include "gemm256w.hpp"
+
 template <bool OUT_F32, int MI, bool F8 = false, bool BNN = false>
 __global__ __launch_bounds__(512, 2) void gemm256_k(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -526,6 +531,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sk_k(const GemmParams p) {
 
 }  // namespace
 
+// internal (tools/ubench/gemm_w4_bench, tests): 1 = the bf16 NT launches run the four-wave form (gemm256w_k), 0 = the eight-wave form
+static int& w4_mode() { static int mode = VM_GEMM_W4_DEFAULT; return mode; }
+extern "C" int vm_gemm_w4_mode_(int mode) { if (mode < 0 || mode > 1) return VM_ERR_BAD_ARG; w4_mode() = mode; return VM_OK; }
+extern "C" int vm_gemm_w4_mode_get_(void) { return w4_mode(); }
+
 // called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles; f8 != 0: e4m3 main operands (vm_gemm_fp8)
 extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented, int tile_rows, int f8, void* stream) {
   // f8: 0 bf16 NT, 1 e4m3 NT, 2 bf16 with the weight in NN form (p.b_nn)
@@ -536,10 +546,12 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   static std::once_flag attr_once;          // (called from the main thread and from autograd's backward thread)
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
-    const void* fns[10] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+    const void* fns[14] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
                           (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
                           (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>,
-                          (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>};
+                          (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>,
+                          (const void*)gemm256w_k<false, 8>, (const void*)gemm256w_k<true, 8>, (const void*)gemm256w_k<false, 6>,
+                          (const void*)gemm256w_k<true, 6>};
     bool ok = true;
     for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) == hipSuccess;
     attr_ok = ok;
@@ -555,6 +567,10 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   } else if (f8) {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
+  } else if (w4_mode() && p.K >= 128) {
+    const dim3 block4(256);
+    if (tile_rows == 256) { if (out_f32) hipLaunchKernelGGL((gemm256w_k<true, 8>), grid, block4, LDS_BYTES2, st, p); else hipLaunchKernelGGL((gemm256w_k<false, 8>), grid, block4, LDS_BYTES2, st, p); }
+    else { if (out_f32) hipLaunchKernelGGL((gemm256w_k<true, 6>), grid, block4, LDS_BYTES2, st, p); else hipLaunchKernelGGL((gemm256w_k<false, 6>), grid, block4, LDS_BYTES2, st, p); }
   } else {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, false); else VM_G256_LAUNCH(false, 4, false); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, false); else VM_G256_LAUNCH(false, 3, false); }
