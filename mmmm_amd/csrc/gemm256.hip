@@ -24,6 +24,7 @@ namespace {
 #ifndef VM_GEMM_W4_DEFAULT
 #define VM_GEMM_W4_DEFAULT 0
 #endif
+constexpr int W4_LDS_BYTES = 160 * 1024;   // four-wave form: two 64 KiB stages + 4 x 8 KiB output slabs
 constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
 constexpr int STAGE_BYTES2 = 4 * HALF_BYTES;
 constexpr int LDS_BYTES2 = 2 * STAGE_BYTES2;
@@ -546,14 +547,13 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   static std::once_flag attr_once;          // (called from the main thread and from autograd's backward thread)
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
-    const void* fns[14] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+    const void* fns[12] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
                           (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
                           (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>,
                           (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>,
-                          (const void*)gemm256w_k<false, 8>, (const void*)gemm256w_k<true, 8>, (const void*)gemm256w_k<false, 6>,
-                          (const void*)gemm256w_k<true, 6>};
+                          (const void*)gemm256w_k<8>, (const void*)gemm256w_k<6>};
     bool ok = true;
-    for (const void* f : fns) ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2) == hipSuccess;
+    for (int i = 0; i < 12; ++i) ok = ok && hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 10 ? LDS_BYTES2 : W4_LDS_BYTES) == hipSuccess;
     attr_ok = ok;
   });
   if (!attr_ok) return VM_ERR_LAUNCH;
@@ -567,10 +567,14 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   } else if (f8) {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
-  } else if (w4_mode() && p.K >= 128) {
-    const dim3 block4(256);
-    if (tile_rows == 256) { if (out_f32) hipLaunchKernelGGL((gemm256w_k<true, 8>), grid, block4, LDS_BYTES2, st, p); else hipLaunchKernelGGL((gemm256w_k<false, 8>), grid, block4, LDS_BYTES2, st, p); }
-    else { if (out_f32) hipLaunchKernelGGL((gemm256w_k<true, 6>), grid, block4, LDS_BYTES2, st, p); else hipLaunchKernelGGL((gemm256w_k<false, 6>), grid, block4, LDS_BYTES2, st, p); }
+  } else if (w4_mode() && p.K >= 128 && !out_f32 && p.act == VM_ACT_NONE) {
+    // the four-wave form (bf16 output, no fused activation) is persistent: one workgroup per CU walks the tile list (gemm256w.hpp);
+    // 128 KiB of stages + 32 KiB of output slabs
+    static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+    const int tiles = p.tiles_m * p.tiles_n;
+    const dim3 grid4(tiles < cus ? tiles : cus), block4(256);
+    if (tile_rows == 256) hipLaunchKernelGGL((gemm256w_k<8>), grid4, block4, W4_LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm256w_k<6>), grid4, block4, W4_LDS_BYTES, st, p);
   } else {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, false); else VM_G256_LAUNCH(false, 4, false); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, false); else VM_G256_LAUNCH(false, 3, false); }

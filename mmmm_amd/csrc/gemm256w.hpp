@@ -13,18 +13,18 @@
 constexpr int W4X = VM_W4_EXPERIMENT;
 constexpr int W4X_SCHED_MASK = 0xFF00;
 
-// One MFMA of the four-wave body. The accumulator operand is constrained to the ACCUMULATOR half of the register file ("+a"): with the
-// builtin, hipcc's allocator — 256 accumulator registers live across the whole K loop, no spare one — shuffled accumulator tiles between
-// the two halves inside the loop (per K-tile and wave 70-200 v_accvgpr_read / _write / _mov and 10-30 s_nop next to the 128 MFMAs: the
-// MFMA-only knock-out of the loop ran at 1 600 TFLOP/s where the bare instruction stream sustains 2 100). As inline assembly the tiles
-// never move. hipcc does not know what the statement is (guide section 5.7): the operands' waits are still the compiler's (they are
-// ordinary "v" inputs), the wait states between the LAST MFMA and the first non-MFMA reader of an accumulator are ours (w4_mfma_drain).
+// One MFMA of the four-wave body: the builtin. (An inline-assembly form with the accumulator constrained to the accumulator file ("+a") was
+// built first, when an epilogue loop that the unroller gave up on had turned the accumulators into a scratch array and the allocator shuffled
+// tiles between the register halves inside the K loop; it ran, and it was WRONG for the 192-row tile with a LoRA extension: hipcc does not
+// know that such a statement is an MFMA, and wherever it places a v_accvgpr_read / _write of its own next to one, the wait states an MFMA's
+// result needs are missing — guide section 5.7 item 4. With every accumulator index a compile-time constant the builtin's loops carry no
+// accumulator moves at all. -DVM_W4_EXPERIMENT=512 keeps the assembly form for the record.)
 __device__ __forceinline__ void w4_mfma(f32x4_t& acc, const bf16x8_t& b, const bf16x8_t& a) {
-  if constexpr (W4X & 512) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
-  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+  if constexpr (W4X & 512) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
 }
 __device__ __forceinline__ void w4_mfma_drain() {
-  if constexpr (!(W4X & 512)) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if constexpr (W4X & 512) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 // ====================================================================================================================
@@ -36,7 +36,8 @@ __device__ __forceinline__ void w4_mfma_drain() {
 // K loop is software-pipelined INSIDE the wave —
 //   * a K-tile is two 32-deep substeps; the 64 (TA = 8) MFMAs of a substep run from one fragment set (8 A + 8 B fragments, 64
 //     VGPRs) while the 16 ds_read_b128 of the NEXT substep fill the other set, two reads behind every eight MFMAs;
-//   * the accumulators (64 tiles x 4 = 256 registers) live in the accumulator half of the unified register file;
+//   * the accumulators (64 tiles x 4 = 256 registers) live in the accumulator half of the unified register file (hipcc puts them there by
+//     itself as long as every accumulator index is a compile-time constant);
 //   * LDS: two stages of (A 256 x 128 B | B 256 x 128 B), row-major with the 16-byte chunk XOR (row & 7) applied to the SOURCE
 //     address of the LDS-DMA (guide rule 21) — the image of gemm_nt_k;
 //   * ONE barrier per K-tile, between its substeps: in front of it every wave has received its second-substep fragments (the last
@@ -44,110 +45,107 @@ __device__ __forceinline__ void w4_mfma_drain() {
 //     the MFMAs of tile t - 1's second substep); behind it the reads of tile t + 1 and the DMA of tile t + 2 (into the stage just
 //     vacated) are legal. 14-16 DMA pieces per wave and K-tile, two behind every eight MFMAs of a second substep.
 // Same K order per output element as the eight-wave form (extension tiles, then the main tiles, k ascending): bit-identical results.
-// Flush of a full ROWS x 128 bf16 slab (interior tile, 16-byte aligned rows of C and of the residual): no per-row predicates, every LDS read
-// and every residual load of a batch of 8 rows-of-4 issued before the first store — one wave alone on its SIMD has nobody to hide a
-// read -> wait -> store chain behind (epi_flush's predicated form cost this kernel 17 us per tile).
-template <int ROWS>
-__device__ __forceinline__ void w4_flush_full(const char* slab, const GemmParams& p, int64_t m0, int n0, int lane) {
-  constexpr int PITCH = EpiSlab<ROWS, 128>::PITCH;
-  const int ch = lane & 15, rr = lane >> 4;                 // 16 chunks of 16 B per row, 4 rows per wave-instruction
-  unsigned short* cbase = (unsigned short*)p.C + (m0 + rr) * p.ldc + n0 + ch * 8;
-  const char* sbase = slab + rr * PITCH + ch * 16;
-  const unsigned short* rp = (const unsigned short*)p.residual;
-  constexpr int NIT = ROWS / 4, BATCH = 8;
-#pragma unroll
-  for (int b0 = 0; b0 < NIT; b0 += BATCH) {
-    u16x8_t v[BATCH], rv[BATCH];
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k)
-      if (b0 + k < NIT) v[k] = *reinterpret_cast<const u16x8_t*>(sbase + (b0 + k) * 4 * PITCH);
-    if (rp) {
-      const unsigned short* rbase = rp + (m0 + rr) * p.ldr + n0 + ch * 8;
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k)
-        if (b0 + k < NIT) rv[k] = *reinterpret_cast<const u16x8_t*>(rbase + (int64_t)(b0 + k) * 4 * p.ldr);
-#pragma unroll
-      for (int k = 0; k < BATCH; ++k)
-        if (b0 + k < NIT) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[k][e] = f2bf(bf2f(v[k][e]) + bf2f(rv[k][e]));
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k)
-      if (b0 + k < NIT) *reinterpret_cast<u16x8_t*>(cbase + (int64_t)(b0 + k) * 4 * p.ldc) = v[k];
-  }
-}
+//
+// PERSISTENT: one workgroup per CU (grid = min(tiles, CUs)) walks tiles v, v + W, v + 2 W, ... of the GROUP_M-grouped, XCD-contiguous tile
+// order. What that buys is the seam between two tiles: behind the last K-tile's barrier both LDS stages are free, so the NEXT tile's
+// first two K-tiles are requested BEFORE the current tile's epilogue (their HBM / L2 latency runs under the conversion and the slab
+// round trip), and the epilogue's global stores are never waited for — they drain under the next tile's K loop (one workgroup per
+// tile paid the prologue's latency and the drain of 128 KiB of stores per tile with nothing to hide them: 8-13 us per tile, measured
+// with the epilogue knocked out). The output slabs live in the 32 KiB of LDS behind the two 64 KiB stages (8 KiB per wave: 32 rows x
+// 256 B, 16-byte chunks XOR (row & 15) — conflict-free for the row-of-4 flush reads, two-way for the 8-byte fragment writes).
+// vmcnt is ONE in-order queue for LDS-DMA pieces and stores: [tile's K-tile 0 pieces][K-tile 1 pieces][previous tile's stores] is the order
+// at a seam, so the first two waits of a tile leave exactly the younger operations outstanding (their count is known on the fast path;
+// any other epilogue path declares "unknown" and the tile starts with full waits).
 
-template <bool OUT_F32, int TA>
-__device__ __forceinline__ void gemm256w_tile(const GemmParams& p, char* smem, const int tid, int tm, int tn) {
+// bf16 output, no fused activation (the launcher sends everything else to the eight-wave form)
+// One tile of the persistent loop (`first`: the workgroup's first tile — its prologue is issued here, not by a predecessor). EVERYTHING derived
+// from the lane id is derived inside, from the laundered `tid` the caller hands over per tile: as invariants of the tile loop hipcc computed the
+// ~60 lane-dependent addresses (DMA offsets, fragment offsets, slab and row addresses) once, kept them live across the K loop, spilled them, and
+// every reload from scratch is a vector-memory operation behind an s_waitcnt vmcnt(0) — in front of each LDS-DMA inside the K loop, and pass by
+// pass through the epilogue, where it drained the next tile's prologue and this tile's stores. Across tiles only scalars survive.
+// Returns the id of the next tile of this workgroup (< 0: none); `younger` in / out: see ktile.
+template <int TA>
+__device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const int id, const int id_end, const int id_step, const bool first, int& younger) {
+  // (the dynamic LDS is named HERE, not handed in as a `char*`: through a generic pointer hipcc no longer saw that the LDS-DMA destination is
+  // wave-uniform and wrapped every piece in a waterfall loop — guide T20)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BMT = 32 * TA;           // tile rows: 256 (TA = 8) or 192 (TA = 6)
   constexpr int WR = 16 * TA;            // rows of one wave row
   constexpr int OPB = 256 * 128;         // LDS bytes of one operand tile (A occupies its first BMT rows)
   constexpr int STG = 2 * OPB;
+  constexpr int SLAB0 = 2 * STG;         // the output slabs: 4 x 8 KiB behind the stages
   constexpr int NP = TA + 8;             // LDS-DMA pieces per wave and K-tile
+  constexpr int NPASS = TA / 2;          // epilogue passes of 32 rows
+  constexpr int NSTORE = NPASS * 8;      // global stores per wave and tile on the interior path
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-
-  int row0, nrows, seg;
-  gemm_tile_rows<BMT>(p, tm, row0, nrows, seg);
-  if (nrows <= 0) return;
-  const int n0 = tn * 256;
-  const int ncols = min(256, p.N - n0);
-  const char* Bw = seg ? p.B1 : p.B0;
-  const char* B2w = seg ? p.B2_1 : p.B2_0;
+  struct Tile { int row0, nrows, seg, n0, ncols; __amdgpu_buffer_rsrc_t rA, rB, rA2, rB2; };
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(p.A, (int64_t)row0 * lda_b, nrows * lda_b);
-  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bw, (int64_t)n0 * ldb_b, ncols * ldb_b);
   const int kt_ext = p.K2 / 64, kt_total = kt_ext + p.K / 64;
-  __amdgpu_buffer_rsrc_t rA2 = rA, rB2 = rB;
-  int lda2_b = 0, ldb2_b = 0;
-  if (kt_ext > 0) {
-    lda2_b = (int)p.lda2 * 2; ldb2_b = (int)p.ldb2 * 2;
-    rA2 = make_rsrc(p.A2, (int64_t)row0 * lda2_b, nrows * lda2_b);
-    rB2 = make_rsrc(B2w, (int64_t)n0 * ldb2_b, ncols * ldb2_b);
-  }
+  const int lda2_b = kt_ext ? (int)p.lda2 * 2 : 0, ldb2_b = kt_ext ? (int)p.ldb2 * 2 : 0;
+  // rows / columns of tile `id`; false: the tile has no rows (the token-routed form launches an upper bound of tile rows)
+  auto locate = [&](int id, Tile& tl) -> bool {
+    const int per_group = GROUP_M * p.tiles_n;
+    const int g = id / per_group, gm0 = g * GROUP_M, gsz = min(GROUP_M, p.tiles_m - gm0), rem = id - g * per_group;
+    const int tm = gm0 + rem % gsz, tn = rem / gsz;
+    gemm_tile_rows<BMT>(p, tm, tl.row0, tl.nrows, tl.seg);
+    tl.n0 = tn * 256;
+    tl.ncols = min(256, p.N - tl.n0);
+    return tl.nrows > 0;
+  };
+  auto describe = [&](Tile& tl) {
+    tl.rA = make_rsrc(p.A, (int64_t)tl.row0 * lda_b, tl.nrows * lda_b);
+    tl.rB = make_rsrc(tl.seg ? p.B1 : p.B0, (int64_t)tl.n0 * ldb_b, tl.ncols * ldb_b);
+    tl.rA2 = tl.rA; tl.rB2 = tl.rB;
+    if (kt_ext > 0) {
+      tl.rA2 = make_rsrc(p.A2, (int64_t)tl.row0 * lda2_b, tl.nrows * lda2_b);
+      tl.rB2 = make_rsrc(tl.seg ? p.B2_1 : p.B2_0, (int64_t)tl.n0 * ldb2_b, tl.ncols * ldb2_b);
+    }
+  };
+  auto find = [&](int id, Tile& tl) -> int {      // first tile with rows at or after `id` in this workgroup's list, -1: none
+    for (; id < id_end; id += id_step)
+      if (locate(id, tl)) return id;
+    return -1;
+  };
+
   // piece q of this wave: rows 8 (wave + 4 q) .. + 7 of the operand tile, 128 B each; lane -> (row r8, LDS slot): source chunk slot ^ r8
   const int r8 = lane >> 3, c16 = ((lane & 7) ^ r8) * 16;
   const int prow = wave * 8 + r8;
-  i32x4_t sink[(W4X & 1024) ? NP : 1];
-  // per-lane byte offsets of this wave's pieces inside the MAIN operands (loop invariants: the K-tile travels in the scalar offset)
+  // per-lane byte offsets of this wave's pieces inside the MAIN operands (invariant over K-tiles: the K-tile travels in the scalar offset)
   int voA[TA], voB[8];
 #pragma unroll
   for (int q = 0; q < TA; ++q) voA[q] = (prow + 32 * q) * lda_b + c16;
 #pragma unroll
   for (int q = 0; q < 8; ++q) voB[q] = (prow + 32 * q) * ldb_b + c16;
-  // idx < TA: A piece idx, else B piece idx - TA (compile-time after unrolling). MAIN: tile t is known to be a main tile (no selects)
-  auto piece = [&](int t, int idx, auto main_tag) {
+  // idx < TA: A piece idx, else B piece idx - TA (compile-time after unrolling). MAIN: K-tile t is known to be a main tile (no selects)
+  auto piece = [&](const Tile& tl, int t, int idx, auto main_tag) {
     constexpr bool MAIN = decltype(main_tag)::value;
     const bool ext = !MAIN && t < kt_ext;
-    const int koff = (ext ? t : t - kt_ext) * 128;
+    // (provably wave-uniform for hipcc: with the K-tile counter in a vector register it wrapped every piece in a waterfall loop over the scalar offset)
+    const int koff = __builtin_amdgcn_readfirstlane((ext ? t : t - kt_ext) * 128);
     const bool isb = idx >= TA;
     const int q = isb ? idx - TA : idx;
     char* dst = smem + (t & 1) * STG + (isb ? OPB : 0) + (wave + 4 * q) * 1024;
     const int vo = MAIN ? (isb ? voB[q] : voA[q]) : (prow + 32 * q) * (isb ? (ext ? ldb2_b : ldb_b) : (ext ? lda2_b : lda_b)) + c16;
-    const __amdgpu_buffer_rsrc_t rs = MAIN ? (isb ? rB : rA) : (isb ? (ext ? rB2 : rB) : (ext ? rA2 : rA));
-    if constexpr (W4X & 1024) {      // timing experiment: the same bytes as a plain load into registers (nothing reaches the LDS: results wrong)
-      sink[idx] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, koff, 0);
-      (void)dst;
-    } else
+    const __amdgpu_buffer_rsrc_t rs = MAIN ? (isb ? tl.rB : tl.rA) : (isb ? (ext ? tl.rB2 : tl.rB) : (ext ? tl.rA2 : tl.rA));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, koff, 0, 0);
+  };
+  auto prologue = [&](const Tile& tl) {          // K-tiles 0 and 1 of a tile (the launcher guarantees >= 2 main K-tiles)
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 0, q, std::false_type{}); }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 1, q, std::false_type{}); }
   };
 
   f32x4_t acc[TA][8];
-#pragma unroll
-  for (int i = 0; i < TA; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   bf16x8_t fa[2][TA], fb[2][8];      // fragment sets: [set][tile]; set 0 = first substep (k 0..31), set 1 = second
-
-  const int frow = lane & 15, fq = lane >> 4;
-  const int slot0 = fq ^ (frow & 7);
-  const int offk[2] = {frow * 128 + slot0 * 16, frow * 128 + (slot0 ^ 4) * 16};
+  const int frow_ = lane & 15, fq_ = lane >> 4;
+  const int slot0 = fq_ ^ (frow_ & 7);
+  const int offk[2] = {frow_ * 128 + slot0 * 16, frow_ * 128 + (slot0 ^ 4) * 16};
   const int a_base = wm * WR * 128, b_base = OPB + wn * 128 * 128;
   // fragment idx of substep ks out of stage `st` into set `set`: idx < 8 a B tile, else an A tile — in the order the next substep consumes
-  // them (its first row of MFMAs takes all eight B fragments and A tile 0: read last, they would be waited for at every substep start)
+  // them (its first row of MFMAs takes all eight B fragments and A tile 0)
   auto fread = [&](const char* st, int ks, int set, int idx) {
     if (idx < 8) fb[set][idx] = *reinterpret_cast<const bf16x8_t*>(st + b_base + idx * 2048 + offk[ks]);
     else fa[set][idx - 8] = *reinterpret_cast<const bf16x8_t*>(st + a_base + (idx - 8) * 2048 + offk[ks]);
@@ -157,14 +155,16 @@ __device__ __forceinline__ void gemm256w_tile(const GemmParams& p, char* smem, c
   // A single wave on its SIMD issues in order: an MFMA keeps the matrix pipe busy for 16 cycles and the issue port for 8 of them, every
   // other instruction of the wave costs >= 4 issue cycles — so the companions (fragment reads, DMA pieces with their M0 write) are dealt
   // out ONE PER MFMA SLOT and the order is pinned slot by slot. Clustered behind a row of eight MFMAs (2 reads + 2 pieces + their scalar
-  // set-up, ~40 issue cycles) they left the matrix pipe idle for ~30 cycles per row, a quarter of the loop.
+  // set-up, ~40 issue cycles) they left the matrix pipe idle for ~30 cycles per row, a quarter of the loop (measured: 8192^3 854 -> 766 us).
   // Slot k of a substep = MFMA (i = k / 8, j = k % 8). Reads go to slots 4 r + 1 (r-th fragment), pieces to slots 4 q + 3.
   constexpr int RSTEP = NS / NF >= 4 ? 4 : NS / NF, PSTEP = NS / NP >= 4 ? 4 : NS / NP;
 
-  // one K-tile. H1: tile t + 1 exists (its first-substep fragments are read behind the second substep); H2: tile t + 2 exists (its DMA
-  // is issued behind the second substep, into the stage this tile leaves); MAIN2: tile t + 2 is a main tile for certain
-  auto ktile = [&](int t, auto h1_tag, auto h2_tag, auto main2_tag) {
-    constexpr bool H1 = decltype(h1_tag)::value, H2 = decltype(h2_tag)::value;
+  // one K-tile. H1: K-tile t + 1 exists (its first-substep fragments are read behind the second substep); H2: K-tile t + 2 exists (its DMA
+  // is issued behind the second substep, into the stage this K-tile leaves); MAIN2: K-tile t + 2 is a main tile for certain.
+  // `younger`: vector-memory operations issued AFTER the pieces of K-tile t + 1 that may still be in flight at the barrier (the previous
+  // tile's stores at a seam: NSTORE, or -1 = unknown -> wait for everything); 0 in the steady state
+  auto ktile = [&](const Tile& tl, int t, int younger, auto first_tag, auto h1_tag, auto h2_tag, auto main2_tag) {
+    constexpr bool H1 = decltype(h1_tag)::value, H2 = decltype(h2_tag)::value, FIRST = decltype(first_tag)::value;
     const char* cur = smem + (t & 1) * STG;
     const char* nxt = smem + ((t + 1) & 1) * STG;
     // ---- substep 0: MFMAs from set 0, second-substep fragments into set 1 (the reads end well in front of the barrier's lgkmcnt(0))
@@ -172,139 +172,225 @@ __device__ __forceinline__ void gemm256w_tile(const GemmParams& p, char* smem, c
     for (int k = 0; k < NS; ++k) {
       w4_mfma(acc[k / 8][k % 8], fb[0][k % 8], fa[0][k / 8]);
       if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(cur, 1, 1, k / RSTEP);
-      if (!(W4X & 256)) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (H1 && !(W4X & 4)) {
-      // every read of the current stage has returned; this wave's pieces of tile t + 1 have landed; then everybody's
-      if constexpr (W4X & 2048) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // timing experiment: the DMA is never waited for (races)
+      // every read of the current stage has returned; this wave's pieces of K-tile t + 1 have landed; then everybody's
+      if (FIRST && younger == NSTORE) { if constexpr (NSTORE == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); }
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      if constexpr (W4X & 1024) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(sink[q]));
-      }
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- substep 1: MFMAs from set 1, tile t + 1's first fragments into set 0, tile t + 2's DMA into the vacated stage
+    // ---- substep 1: MFMAs from set 1, K-tile t + 1's first fragments into set 0, K-tile t + 2's DMA into the vacated stage
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       w4_mfma(acc[k / 8][k % 8], fb[1][k % 8], fa[1][k / 8]);
       if constexpr (H1) { if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(nxt, 0, 0, k / RSTEP); }
-      if constexpr (H2) { if (k % PSTEP == PSTEP - 1 && k / PSTEP < NP && !(W4X & 1)) piece(t + 2, k / PSTEP, main2_tag); }
-      if (!(W4X & 256)) __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto ext_scale = [&]() {
-    if (p.drop_p > 0.f) {
-#pragma unroll
-      for (int i = 0; i < TA; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          gemm_ext_scale4<true>(p, row0 + wm * WR + i * 16 + frow, n0 + wn * 128 + j * 16 + fq * 4, acc[i][j]);
-    } else if (p.alpha2 != 1.f) {
-#pragma unroll
-      for (int i = 0; i < TA; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] *= p.alpha2;
+      if constexpr (H2) { if (k % PSTEP == PSTEP - 1 && k / PSTEP < NP && !(W4X & 1)) piece(tl, t + 2, k / PSTEP, main2_tag); }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // prologue: tiles 0 and 1 on their way, tile 0 landed, its first fragments read
-#pragma unroll
-  for (int q = 0; q < NP; ++q) piece(0, q, std::false_type{});
-#pragma unroll
-  for (int q = 0; q < NP; ++q) piece(1, q, std::false_type{});
-  if constexpr (NP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int f = 0; f < NF; ++f) fread(smem, 0, 0, f);
-
-  int t = 0;
-  // (the scale of the LoRA extension sits BETWEEN the loops, never inside one: see the eight-wave form. The launcher sends a call here only
-  // with >= 2 main K-tiles behind the extension, so every extension tile has two successors and runs the full body)
-  if (kt_ext > 0) {
-    for (; t < kt_ext; ++t) ktile(t, std::true_type{}, std::true_type{}, std::false_type{});
-    w4_mfma_drain();
-    ext_scale();
-  }
-  for (; t + 2 < kt_total; ++t) ktile(t, std::true_type{}, std::true_type{}, std::true_type{});
-  ktile(t, std::true_type{}, std::false_type{}, std::true_type{});
-  ktile(t + 1, std::false_type{}, std::false_type{}, std::true_type{});
-  w4_mfma_drain();
-  __builtin_amdgcn_s_barrier();          // every wave is past its last LDS read: the stages become the output slabs
-
-  const void* bias = seg ? p.bias1 : p.bias0;
-  if (W4X & 8) {          // (every accumulator stays live: guide rule 17)
-    float sum = 0.f;
+  Tile cur;
+  locate(id, cur);
+  describe(cur);
+  if (first) prologue(cur);
+  {
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sum == 123.456f) ((float*)p.C)[0] = 1.f;
-    return;
-  }
-  if (OUT_F32) {
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 has landed (K-tile 1's pieces and, at a seam, the previous tile's stores are younger and may stay in flight)
+    if (W4X & 1) {}
+    else if (younger == NSTORE) { if constexpr (NP + NSTORE == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); }
+    else if (younger == 0) { if constexpr (NP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < TA; ++i) {
-      const int ml = wm * WR + i * 16 + frow;
-      if (ml >= nrows) continue;
+    for (int f = 0; f < NF; ++f) fread(smem, 0, 0, f);
+
+    // (the scale of the LoRA extension sits BETWEEN the loops, never inside one: see the eight-wave form. The launcher sends a call here only
+    // with >= 2 main K-tiles behind the extension, so every extension tile has two successors and runs the full body)
+    // (the first K-tile of a tile is peeled: it alone looks at `younger`; kt_total >= 3 when there is an extension, >= 2 without. ONE copy of
+    // the main loop and of the two tail bodies serves both cases: with a copy per case hipcc's allocation of the extension case's copy spilled)
+    const std::true_type yes{};
+    const std::false_type no{};
+    int t = 1;
+    if (kt_ext > 0) {
+      ktile(cur, 0, younger, yes, yes, yes, no);
+      for (; t < kt_ext; ++t) ktile(cur, t, 0, no, yes, yes, no);
+      w4_mfma_drain();
+      if (p.drop_p > 0.f) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            gemm_ext_scale4<true>(p, cur.row0 + wm * WR + i * 16 + frow_, cur.n0 + wn * 128 + j * 16 + fq_ * 4, acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);       // one tile's hash at a time: interleaved for ILP, the 64 hashes spilled the accumulators
+          }
+      } else if (p.alpha2 != 1.f) {
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[i][j] *= p.alpha2;
+      }
+    } else if (kt_total > 2) {
+      ktile(cur, 0, younger, yes, yes, yes, yes);
+    } else {
+      ktile(cur, 0, younger, yes, yes, no, yes);
+    }
+    for (; t + 2 < kt_total; ++t) ktile(cur, t, 0, no, yes, yes, yes);
+    if (t + 1 < kt_total) { ktile(cur, t, 0, no, yes, no, yes); ++t; }
+    if (t < kt_total) ktile(cur, t, 0, no, no, no, yes);
+    w4_mfma_drain();
+    __builtin_amdgcn_s_barrier();          // every wave is past its last LDS read: both stages are free
+
+    // ---- the seam: the next tile's first two K-tiles go out before this tile's epilogue. Only what the epilogue needs of THIS tile stays
+    // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
+    const int row0 = cur.row0, nrows = cur.nrows, n0 = cur.n0, ncols = cur.ncols, seg = cur.seg;
+    const int nid = find(id + id_step, cur);
+    if (nid >= 0) { describe(cur); prologue(cur); }
+
+    // ---- epilogue: accumulators (+ bias) -> bf16 -> this wave's slab -> whole 256-byte rows of C (+ residual), 32 rows per pass
+    int stores = -1;                       // global stores this wave issued for the tile, if the path knows (-1: unknown)
+    if (W4X & 8) {          // (every accumulator stays live: guide rule 17)
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (sum == 123.456f) ((float*)p.C)[0] = 1.f;
+    } else {
+      // (laundered once more: the slab / row addresses are computed HERE, behind the K loop, not in front of it)
+      int frow = frow_, fq = fq_, lane_e = lane;
+      asm volatile("" : "+v"(frow), "+v"(fq), "+v"(lane_e));
+      char* slab = smem + SLAB0 + wave * 8192;
+      const unsigned short* bias = (const unsigned short*)(seg ? p.bias1 : p.bias0);
+      const unsigned short* rp = (const unsigned short*)p.residual;
+      const int rows_left = nrows - wm * WR, cols_left = ncols - wn * 128;      // of this wave's WR x 128 block
+      const bool vec_ok = (p.ldc % 8 == 0) && (!rp || p.ldr % 8 == 0);
+      const bool interior = rows_left >= WR && cols_left >= 128 && vec_ok;
+      // bias of the lane's column groups (guarded element loads: once per tile, any alignment, ragged N)
+      f32x4_t bv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int nl = wn * 128 + j * 16 + fq * 4;
-        if (nl >= ncols) continue;
-        gemm_store4<true>(p, bias, row0 + ml, n0 + nl, ncols - nl, acc[i][j]);
+        bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const int c = j * 16 + fq * 4 + e; if (c < cols_left) bv[j][e] = bf2f(bias[n0 + wn * 128 + c]); }
+        }
       }
-    }
-  } else {
-    constexpr int HR = 8 * TA;            // rows of one slab pass (half a wave row): 64 or 48
-    typedef EpiSlab<HR, 128> Slab;
-    char* slab = smem + wave * Slab::BYTES;
-    const bool plain = bias == nullptr && p.act == VM_ACT_NONE;
-    const bool fast_bias = bias != nullptr && p.act == VM_ACT_NONE && ncols - wn * 128 >= 128 && ((uintptr_t)bias & 7) == 0;
-    f32x4_t bv[8];
-    if (fast_bias) {
+      const int ch = lane_e & 15, rr = lane_e >> 4;             // flush: 16 chunks of 16 B per row, 4 rows per wave-instruction
+      // 32 rows per pass: A tiles 2 ps, 2 ps + 1 (`ps` is a compile-time tag and the passes are separate calls: a loop the unroller gives
+      // up on turns the accumulator indices into run-time ones and the 256 accumulators into a scratch array)
+      auto pass = [&](auto ps_tag) {
+        constexpr int ps = decltype(ps_tag)::value;
+        if (ps > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous pass's slab reads are in registers
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = epi_bias4(bias, n0 + wn * 128 + j * 16 + fq * 4);
-    }
-    // (the two passes are two calls with a compile-time `half`: a `for (half)` loop the unroller gives up on turns every accumulator index into
-    // a run-time one, and the 256 accumulators into a scratch array that each MFMA of the K loop then writes through)
-    // (MODE is a compile-time tag too and the dispatch sits OUTSIDE the loops: with `if (fast_bias) .. else if (plain) ..` inside the loop body hipcc
-    // merged the three forms into one per-element branch ladder — 460 instructions and 35 branches per 4 outputs, 14 us per tile)
-    auto pass = [&](auto half_tag, auto mode_tag) {
-      constexpr int half = decltype(half_tag)::value, MODE = decltype(mode_tag)::value;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int i = 0; i < TA / 2; ++i)
+          for (int j = 0; j < 8; ++j) {
+            f32x4_t a = acc[2 * ps + ii][j];
+            if constexpr (W4X & 32) { asm volatile("" :: "v"(a)); continue; }
+            if (bias) a += bv[j];
+            const u16x4_t o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+            *reinterpret_cast<u16x4_t*>(slab + (ii * 16 + frow) * 256 + (((2 * j + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8) = o;
+          }
+        // the flush reads what the fill wrote through another vector type: nothing but this fence tells hipcc that they alias (without it the
+        // reads were scheduled above the later writes). The LDS itself executes a wave's accesses in order: no wait is needed.
+        asm volatile("" ::: "memory");
+        if constexpr (W4X & 16) return;
+        const int64_t m0 = row0 + wm * WR + ps * 32;
+        unsigned short* cp = (unsigned short*)p.C + n0 + wn * 128 + ch * 8;
+        if (interior) {
+          u16x8_t vv[8], rv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4_t& a = acc[half * (TA / 2) + i][j];
-          if constexpr (W4X & 32) { asm volatile("" :: "v"(a)); continue; }
-          if constexpr (MODE == 2) epi_put4<2>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, a, bv[j]);
-          else if constexpr (MODE == 0) epi_put4<0>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, 0, 4, a);
-          else {
-            const int nl = wn * 128 + j * 16 + fq * 4;
-            epi_put4<1>(slab, Slab::PITCH, i * 16 + frow, j * 16 + fq * 4, p, bias, n0 + nl, ncols - nl, a);
+          for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + rr;
+            vv[it] = *reinterpret_cast<const u16x8_t*>(slab + row * 256 + ((ch ^ (row & 15)) << 4));
+          }
+          if (rp) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rv[it] = *reinterpret_cast<const u16x8_t*>(rp + (m0 + it * 4 + rr) * p.ldr + n0 + wn * 128 + ch * 8);
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vv[it][e] = f2bf(bf2f(vv[it][e]) + bf2f(rv[it][e]));
+          }
+#pragma unroll
+          for (int it = 0; it < 8; ++it) *reinterpret_cast<u16x8_t*>(cp + (m0 + it * 4 + rr) * p.ldc) = vv[it];
+        } else {
+          // edge tiles / odd leading dimensions: the same slab, row and column predicates, compact code (not performance relevant)
+#pragma unroll 1
+          for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + rr;
+            if (ps * 32 + row >= rows_left || ch * 8 >= cols_left) continue;
+            u16x8_t x = *reinterpret_cast<const u16x8_t*>(slab + row * 256 + ((ch ^ (row & 15)) << 4));
+            const int64_t m = m0 + row;
+            const int nv = min(8, cols_left - ch * 8);
+            if (rp) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (e < nv) x[e] = f2bf(bf2f(x[e]) + bf2f(rp[m * p.ldr + n0 + wn * 128 + ch * 8 + e]));
+            }
+            if (nv == 8 && vec_ok) *reinterpret_cast<u16x8_t*>(cp + m * p.ldc) = x;
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (e < nv) cp[m * p.ldc + e] = x[e];
+            }
           }
         }
-      if constexpr (!(W4X & 16)) {
-        const int rows_left = nrows - wm * WR - half * HR, cols_left = ncols - wn * 128;
-        const bool vec_ok = (p.ldc % 8 == 0) && (!p.residual || p.ldr % 8 == 0);
-        if (rows_left >= HR && cols_left >= 128 && vec_ok) w4_flush_full<HR>(slab, p, row0 + wm * WR + half * HR, n0 + wn * 128, lane);
-        else epi_flush<HR, 128>(slab, p, row0 + wm * WR + half * HR, n0 + wn * 128, rows_left, cols_left, lane);
-      }
-    };
-    const std::integral_constant<int, 0> h0{};
-    const std::integral_constant<int, 1> h1{};
-    if (fast_bias) { pass(h0, std::integral_constant<int, 2>{}); pass(h1, std::integral_constant<int, 2>{}); }
-    else if (plain) { pass(h0, std::integral_constant<int, 0>{}); pass(h1, std::integral_constant<int, 0>{}); }
-    else { pass(h0, std::integral_constant<int, 1>{}); pass(h1, std::integral_constant<int, 1>{}); }
+      };
+      pass(std::integral_constant<int, 0>{});
+      pass(std::integral_constant<int, 1>{});
+      pass(std::integral_constant<int, 2>{});
+      if constexpr (TA == 8) pass(std::integral_constant<int, 3>{});
+      stores = (interior && !rp && !(W4X & 16)) ? NSTORE : -1;
+    }
+    younger = stores;
+    return nid;
   }
 }
 
-template <bool OUT_F32, int TA>
+template <int TA>
 __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn;
-  gemm_tile_id(p, tm, tn);
-  gemm256w_tile<OUT_F32, TA>(p, smem, threadIdx.x, tm, tn);
+  // ---- the tile list of this workgroup. The one-tile-per-workgroup kernels give XCD x (blocks b with b % 8 == x share an L2) one CONTIGUOUS
+  // chunk of the GROUP_M-grouped tile order and the dispatcher walks every chunk front to back, 32 tiles at a time: consecutive rounds of an
+  // XCD are neighbours in tile space (shared operand panels still in its L2 / the Infinity Cache). Same walk here: workgroup (x = b % 8,
+  // slot = b / 8) takes chunk_x[slot], chunk_x[slot + S], ... with S = W / 8 slots per XCD. (W % 8 != 0 only when there are fewer tiles than
+  // CUs — one tile per workgroup, through the same bijective map.)
+  constexpr int BMT = 32 * TA;
+  const int W = gridDim.x;
+  const int T = p.tiles_m * p.tiles_n;
+  int id0, id_end, id_step;
+  {
+    const int b = blockIdx.x, x = b & 7;
+    if (VM_DBG(p, 2)) { id0 = b; id_end = T; id_step = W; }
+    else if (W & 7) { const int q = W >> 3, r = W & 7; id0 = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3); id_end = id0 + 1; id_step = 1; }
+    else {
+      const int q = T >> 3, r = T & 7;
+      const int c0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+      id0 = c0 + (b >> 3); id_end = c0 + q + (x < r ? 1 : 0); id_step = W >> 3;
+    }
+  }
+  // first tile with rows (the token-routed form launches an upper bound of tile rows)
+  int id = -1;
+  for (int c = id0; c < id_end; c += id_step) {
+    const int per_group = GROUP_M * p.tiles_n;
+    const int g = c / per_group, gm0 = g * GROUP_M, gsz = min(GROUP_M, p.tiles_m - gm0), rem = c - g * per_group;
+    int row0, nrows, seg;
+    gemm_tile_rows<BMT>(p, gm0 + rem % gsz, row0, nrows, seg);
+    if (nrows > 0) { id = c; break; }
+  }
+  int younger = 0;            // operations behind the two prologue K-tiles in the queue: none for the first tile
+  bool first = true;
+  if constexpr (W4X & 64) {       // experiment: XCD x starts x * ~3 us late (are the epilogues' store bursts a chip-wide collision?)
+    for (int k = 0; k < (int)(blockIdx.x & 7) * 6; ++k) __builtin_amdgcn_s_sleep(16);
+  }
+  while (id >= 0) {
+    int tid_l = threadIdx.x;
+    asm volatile("" : "+v"(tid_l));
+    id = w4_tile<TA>(p, tid_l, id, id_end, id_step, first, younger);
+    first = false;
+  }
 }
 

@@ -147,12 +147,21 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hs.data(), Csk, cbytes, hipMemcpyDeviceToHost));
     size_t ndiff = 0;
     const size_t esz = s.f32out ? 4 : 2;
+    size_t rowhist[16] = {0}, colhist[16] = {0};
     for (int m = 0; m < s.M; ++m)
       for (int n = 0; n < s.N; ++n) {
         const size_t i = ((size_t)m * ldc + n) * esz;
-        if (std::memcmp(&hd[i], &hs[i], esz) != 0) { if (ndiff < 4) printf("     first differences: m %d n %d\n", m, n); ++ndiff; }
+        if (std::memcmp(&hd[i], &hs[i], esz) != 0) {
+          if (ndiff < 6) {
+            if (s.f32out) { float a, b; std::memcpy(&a, &hd[i], 4); std::memcpy(&b, &hs[i], 4); printf("     first differences: m %d n %d: W8 %g W4 %g\n", m, n, a, b); }
+            else { unsigned short a, b; std::memcpy(&a, &hd[i], 2); std::memcpy(&b, &hs[i], 2); printf("     first differences: m %d n %d: W8 %g (%04x) W4 %g (%04x)\n", m, n, bf2f_host(a), a, bf2f_host(b), b); }
+          }
+          ++ndiff;
+          if (m < 4096 && n < 4096) { rowhist[m / 16 % 16]++; colhist[n / 16 % 16]++; }
+        }
       }
     const bool ok = ndiff == 0;
+    if (!ok) { printf("     by (m / 16) %% 16:"); for (int k = 0; k < 16; ++k) printf(" %zu", rowhist[k]); printf("\n     by (n / 16) %% 16:"); for (int k = 0; k < 16; ++k) printf(" %zu", colhist[k]); printf("\n"); }
     if (!ok) ++fails;
     printf("[%2zu] %-40s check %s: %zu of %zu elements differ\n", si, s.name, ok ? "ok (bit-identical)" : "FAIL", ndiff, (size_t)s.M * s.N);
     (void)stress;
