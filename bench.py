@@ -263,7 +263,7 @@ def gemm_source_digest() -> str:
     """sha256 (first 16 hex digits) over the sources of the dominant GEMM kernel: ties a committed PMC measurement to the code it measured"""
     import hashlib
     h = hashlib.sha256()
-    for f in ('gemm256.hip', 'gemm.hip', 'gemm_common.hpp', 'vm_tile.hpp'):
+    for f in ('gemm256.hip', 'gemm256w.hpp', 'gemm.hip', 'gemm_common.hpp', 'vm_tile.hpp'):
         h.update((ROOT / 'mmmm_amd' / 'csrc' / f).read_bytes())
     return h.hexdigest()[:16]
 

@@ -32,6 +32,8 @@ def _ld(t: torch.Tensor) -> int:
 _GEMM_WS: dict = {}
 GEMM_TAILS = True            # the scheduler may run a launch as full 256-row tiles + a tails launch (vm_gemm_tails_mode_); A/B: bench.py --set kernels.GEMM_TAILS=False
 _gemm_tails_applied = [True]
+GEMM_W4 = 0                  # 1: bf16-output NT launches of the 256-column kernel run the four-wave persistent form (vm_gemm_w4_mode_; profiles/r6_gemm_w4.txt); A/B: bench.py --set kernels.GEMM_W4=1
+_gemm_w4_applied = [0]
 
 
 def gemm_workspace() -> torch.Tensor:
@@ -72,6 +74,9 @@ def gemm(
     if GEMM_TAILS != _gemm_tails_applied[0]:
         hip.call('vm_gemm_tails_mode_', int(bool(GEMM_TAILS)))
         _gemm_tails_applied[0] = GEMM_TAILS
+    if GEMM_W4 != _gemm_w4_applied[0]:
+        hip.call('vm_gemm_w4_mode_', int(GEMM_W4))
+        _gemm_w4_applied[0] = GEMM_W4
     if b_nn:      # `w` is [K, N]: the contraction index is its row (a weight as stored, for dx = dy W); bf16, 256-column kernel only
         assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.dtype == torch.bfloat16 and out is None, (a.shape, w.shape)
         M, K = a.shape
