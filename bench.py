@@ -640,9 +640,9 @@ def main():
         dt = t.item()
     loss_v = float(loss.item())
     # host enqueue time of a step: inside the timed region the host runs ahead of the GPU until the launch queue throttles it, so its
-    # per-step wall time there equals the GPU's. Two more steps (untimed), each started from an idle GPU: time until step() returns.
+    # per-step wall time there equals the GPU's. Five more steps (untimed), each started from an idle GPU: time until step() returns.
     host_enq = []
-    for _ in range(2):
+    for _ in range(5):
         torch.cuda.synchronize()
         h0 = time.perf_counter()
         step()
@@ -668,8 +668,8 @@ def main():
                        'gradient_checkpointing': plan, 'wgrad_side_stream': side_stream_note[0], 'fp8_linears': n_fp8, 'fp32_islands': ('sam / isam_model / vg_proj fp32 on split-bf16 MFMA products: six per product (fp32-exact) everywhere except the 12 blocks of the two SAM-B image encoders, which use three (image_encoder.ENCODER_F32_SPLIT = %d)' % _enc_split()) if w['sam'] else None, 'optimizer': 'clip 1.0 + AdamW, ' + ('one fused kernel per gradient bucket' if args.optimizer == 'flat' else 'torch.optim fused'), 'depth_scale': args.depth_scale,
                        'resample': 'parity UNPINNED for one op on this path: luolib.models.spadop.resample (the position tables [C, 8, 32, 32] -> the image\'s patch grid, every step; visual.py:44-66, image_encoder.py:74-115) lives in an un-vendored submodule absent from /root/reference — mmmm_amd/models/resample.py and the oracle restate it as linear interpolation (align_corners False), and no test can see that guess being wrong'},
             'loss': loss_v,
-            'host_enqueue_ms': min(host_enq),
-            'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min of 2 untimed steps after the timed region); must stay below ms_per_step',
+            'host_enqueue_ms': min(host_enq), 'host_enqueue_median_ms': sorted(host_enq)[len(host_enq) // 2],
+            'host_enqueue_note': 'time until step() has enqueued every launch, from an idle GPU (min / median of 5 untimed steps after the timed region); must stay below ms_per_step',
             # hipMalloc / hipFree calls of the caching allocator inside the timed region (measured harmless: a run with 1 and
             # runs with 43-65 calls in 12 steps take the same time; reserving a large segment up front changes nothing)
             'allocator': {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}

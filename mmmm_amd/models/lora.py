@@ -106,6 +106,10 @@ class Fp8Weights:
         del wt
 
 
+FLAT_LINEAR = True      # a 2-D input goes to the GEMM as it is and the result comes back as it is: without this every tower linear sat between a reshape and a
+                        # view of the same shape (1 100 ViewBackward0 nodes per step, ~10 ms of host enqueue: tools/graph_nodes.py); A/B: bench.py --set models.lora.FLAT_LINEAR=False
+
+
 class Linear(nn.Module):
     """y = x W^T (+ b) (+ s·B A drop(x)); frozen weights keep a transposed copy for the dgrad GEMM."""
 
@@ -212,19 +216,20 @@ class Linear(nn.Module):
         """`fork`: -> (y, x passed through): hand the second output to the block's residual add and the residual's gradient is
         summed into dx by the dgrad GEMM's epilogue (functional.LinearMeta.fork)."""
         shape = x.shape
-        x2 = x.reshape(-1, shape[-1])
-        r2 = residual.reshape(-1, self.out_features) if residual is not None else None
+        flat = x.dim() == 2 and FLAT_LINEAR          # the towers hand over [rows, hidden]: no reshape / view nodes around the linear
+        x2 = x if flat else x.reshape(-1, shape[-1])
+        r2 = (residual if residual.dim() == 2 else residual.reshape(-1, self.out_features)) if residual is not None else None
         need_dx = torch.is_grad_enabled() and x2.requires_grad
         meta = self.meta()
         meta.fork = fork and Fh.FORK_LINEAR
         y = Fh.linear(x2, self.weight, meta=meta, Wt0=self.wt() if need_dx else None, b0=self.bias, A0=self.A, B0=self.B,
                       residual=r2)
         if fork and not meta.fork:
-            return y.view(*shape[:-1], self.out_features), x
+            return (y if flat else y.view(*shape[:-1], self.out_features)), x
         if fork:
             y, xp = y
-            return y.view(*shape[:-1], self.out_features), xp.view(shape)
-        return y.view(*shape[:-1], self.out_features)
+            return (y, xp) if flat else (y.view(*shape[:-1], self.out_features), xp.view(shape))
+        return y if flat else y.view(*shape[:-1], self.out_features)
 
 
 @torch.no_grad()

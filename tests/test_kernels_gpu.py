@@ -371,12 +371,14 @@ def test_vit_layer_with_the_linear_fork_matches_the_default(dev, K, monkeypatch)
         assert rel_err(p1[n], p0[n]) < 2e-2, n
 
 
-@pytest.mark.parametrize('switch', ['NN_DGRAD', 'WGRAD_SIDE_STREAM', 'WGRAD_GROUP_OFF', 'F32_TN_WGRAD_OFF'])
+@pytest.mark.parametrize('switch', ['NN_DGRAD', 'WGRAD_SIDE_STREAM', 'WGRAD_GROUP_OFF', 'F32_TN_WGRAD_OFF', 'FLAT_LINEAR_OFF', 'GEMM_W4'])
 def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch):
     """Alternatives that were measured and left OFF ("dead ends") stay in the library behind module-level switches; each
     is exercised here on a ViT-E-shaped layer with LoRA (dropout on: the mask replay is part of every path) against the default path:
     NN_DGRAD (input gradient from the weight as stored),
-    WGRAD_SIDE_STREAM (factor gradients on a side stream), and the two old fallbacks WGRAD_GROUP = 0 / F32_TN_WGRAD = 0."""
+    WGRAD_SIDE_STREAM (factor gradients on a side stream), the two old fallbacks WGRAD_GROUP = 0 / F32_TN_WGRAD = 0, [r6] models.lora.FLAT_LINEAR = False
+    (a reshape and a view of the same shape around every tower linear: the same kernels, so bit-identical) and kernels.GEMM_W4 = 1 (the four-wave form of the
+    256-column GEMM wherever the scheduler sends a launch there: bit-identical by construction, tests/test_gemm_w4_gpu.py)."""
     from argparse import Namespace
     from mmmm_amd import functional as Fh
     from mmmm_amd.ddp import BucketedGradAllReduce
@@ -407,6 +409,11 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
                 monkeypatch.setattr(Fh, 'WGRAD_GROUP', not on)
             elif switch == 'F32_TN_WGRAD_OFF':
                 monkeypatch.setattr(Fh, 'F32_TN_WGRAD', not on)
+            elif switch == 'FLAT_LINEAR_OFF':
+                from mmmm_amd.models import lora as _lora
+                monkeypatch.setattr(_lora, 'FLAT_LINEAR', not on)
+            elif switch == 'GEMM_W4':
+                monkeypatch.setattr(K, 'GEMM_W4', int(on))
             else:
                 monkeypatch.setattr(Fh, switch, on)
             ddp.zero_grad()
@@ -420,8 +427,14 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
         assert rel_err(y1, y0) < 1e-2 and rel_err(g1, g0) < 2e-2, (switch, rel_err(y1, y0), rel_err(g1, g0))
         for n in p0:
             assert rel_err(p1[n], p0[n]) < 3e-2, (switch, n, rel_err(p1[n], p0[n]))
+        if switch in ('FLAT_LINEAR_OFF', 'GEMM_W4'):
+            assert torch.equal(y1, y0) and torch.equal(g1, g0), switch          # (the norm gains' gradients go through fp32 atomics: not compared bit for bit)
     finally:
         ddp.remove()
+        if switch == 'GEMM_W4':
+            from mmmm_amd import hip as _hip
+            _hip.call('vm_gemm_w4_mode_', 0)
+            K._gemm_w4_applied[0] = 0
 
 
 # ------------------------------------------------------------------ rope

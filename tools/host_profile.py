@@ -72,10 +72,11 @@ def _arm(ctx, *a):
 
 Fh._Linear.backward = staticmethod(_arm)
 pr = cProfile.Profile()
-pr.enable()
 for _ in range(n):
+    torch.cuda.synchronize()          # every profiled step starts on an idle GPU: a launch that finds the queue full WAITS inside hip.call, and
+    pr.enable()                       # three steps enqueued back to back (host 150 ms, GPU 300 ms per step) measured that wait, not the host
     step()
-pr.disable()
+    pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats('tottime').print_stats(28)
