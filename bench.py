@@ -696,7 +696,7 @@ def main():
                 else:
                     traffic_src = (f'profiles/{tf.name} is STALE (kernel sources changed since it was measured: digest {tj.get("source_digest")} '
                                    f'vs {digest}; it held {tj["bytes_per_launch"]:.3e} bytes per launch) — re-run tools/pmc_traffic.sh')
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm256_k / gemm256w_k / gemm_nt_k<bf16> (vm_gemm_bf16)', 'achieved': ach, 'peak': PEAK_BF16_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                                'peak_measured': peak_measured, 'frac_of_measured': (ach / peak_measured) if peak_measured else None,
                                'peak_measured_note': 'sustained rate of bare v_mfma_f32_16x16x32_bf16 on this device, uniform random operands in registers, two waves per SIMD, all CUs, 2 s (second half timed): vm_ubench_mfma_bf16',

@@ -22,7 +22,7 @@
 namespace {
 
 #ifndef VM_GEMM_W4_DEFAULT
-#define VM_GEMM_W4_DEFAULT 0
+#define VM_GEMM_W4_DEFAULT 2
 #endif
 constexpr int W4_LDS_BYTES = 160 * 1024;   // four-wave form: two 64 KiB stages + 4 x 8 KiB output slabs
 constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
@@ -532,9 +532,11 @@ __global__ __launch_bounds__(512, 2) void gemm256sk_k(const GemmParams p) {
 
 }  // namespace
 
-// internal (tools/ubench/gemm_w4_bench, tests): 1 = the bf16 NT launches run the four-wave form (gemm256w_k), 0 = the eight-wave form
+// internal (tools/ubench/gemm_w4_bench, tests, kernels.GEMM_W4): 0 = the eight-wave form everywhere, 1 = bf16 NT launches run the four-wave form (gemm256w_k),
+// 2 = only the launches the scheduler runs on 192-row tiles do (the 192-row body has no register spills and wins 3-8 % with the weight coming from HBM;
+// the 256-row body loses to the eight-wave form as soon as the launch carries a LoRA extension: profiles/r6_gemm_w4.txt, last table)
 static int& w4_mode() { static int mode = VM_GEMM_W4_DEFAULT; return mode; }
-extern "C" int vm_gemm_w4_mode_(int mode) { if (mode < 0 || mode > 1) return VM_ERR_BAD_ARG; w4_mode() = mode; return VM_OK; }
+extern "C" int vm_gemm_w4_mode_(int mode) { if (mode < 0 || mode > 2) return VM_ERR_BAD_ARG; w4_mode() = mode; return VM_OK; }
 extern "C" int vm_gemm_w4_mode_get_(void) { return w4_mode(); }
 
 // called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles; f8 != 0: e4m3 main operands (vm_gemm_fp8)
@@ -567,7 +569,7 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   } else if (f8) {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
-  } else if (w4_mode() && p.K >= 128 && !out_f32 && p.act == VM_ACT_NONE) {
+  } else if ((w4_mode() == 1 || (w4_mode() == 2 && tile_rows == 192)) && p.K >= 192 && !out_f32 && p.act == VM_ACT_NONE) {          // (>= 3 main K-tiles: the weight is staged three deep)
     // the four-wave form (bf16 output, no fused activation) is persistent: one workgroup per CU walks the tile list (gemm256w.hpp);
     // 128 KiB of stages + 32 KiB of output slabs
     static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();

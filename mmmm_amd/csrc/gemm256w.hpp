@@ -38,12 +38,16 @@ __device__ __forceinline__ void w4_mfma_drain() {
 //     VGPRs) while the 16 ds_read_b128 of the NEXT substep fill the other set, two reads behind every eight MFMAs;
 //   * the accumulators (64 tiles x 4 = 256 registers) live in the accumulator half of the unified register file (hipcc puts them there by
 //     itself as long as every accumulator index is a compile-time constant);
-//   * LDS: two stages of (A 256 x 128 B | B 256 x 128 B), row-major with the 16-byte chunk XOR (row & 7) applied to the SOURCE
-//     address of the LDS-DMA (guide rule 21) — the image of gemm_nt_k;
+//   * LDS (160 KiB): the ACTIVATION tile two K-tiles deep, the WEIGHT tile three deep — [A0 | A1 | B0 | B1 | B2], 32 KiB each, row-major with the
+//     16-byte chunk XOR (row & 7) applied to the SOURCE address of the LDS-DMA (guide rule 21), the image of gemm_nt_k. A frozen weight comes from
+//     HBM every time it is used and a launch pays 4-5 % for that with one K-tile of lead (7-12 % in the first version of this kernel, which had two
+//     stages of (A | B) and lost 3 % inside the step for it: profiles/r6_clock_power.txt); the activation was just written and is cache-warm. vmcnt
+//     retires in order, so the deeper operand only keeps its lead if its pieces are the YOUNGEST in the queue when the other operand is waited for:
+//     per K-tile the activation pieces of K-tile t + 2 go out first, then the weight pieces of K-tile t + 3, and the barrier's wait leaves the eight
+//     weight pieces of K-tile t + 2 in flight;
 //   * ONE barrier per K-tile, between its substeps: in front of it every wave has received its second-substep fragments (the last
-//     reads of the current stage) and has waited for its own LDS-DMA pieces of tile t + 1 (issued a whole substep earlier, behind
-//     the MFMAs of tile t - 1's second substep); behind it the reads of tile t + 1 and the DMA of tile t + 2 (into the stage just
-//     vacated) are legal. 14-16 DMA pieces per wave and K-tile, two behind every eight MFMAs of a second substep.
+//     reads of the current stages) and has waited for its own pieces of K-tile t + 1; behind it the reads of K-tile t + 1 and the DMA into the two
+//     stages just vacated are legal. 14-16 DMA pieces per wave and K-tile, one behind every fourth MFMA of a second substep.
 // Same K order per output element as the eight-wave form (extension tiles, then the main tiles, k ascending): bit-identical results.
 //
 // PERSISTENT: one workgroup per CU (grid = min(tiles, CUs)) walks tiles v, v + W, v + 2 W, ... of the GROUP_M-grouped, XCD-contiguous tile
@@ -51,8 +55,9 @@ __device__ __forceinline__ void w4_mfma_drain() {
 // first two K-tiles are requested BEFORE the current tile's epilogue (their HBM / L2 latency runs under the conversion and the slab
 // round trip), and the epilogue's global stores are never waited for — they drain under the next tile's K loop (one workgroup per
 // tile paid the prologue's latency and the drain of 128 KiB of stores per tile with nothing to hide them: 8-13 us per tile, measured
-// with the epilogue knocked out). The output slabs live in the 32 KiB of LDS behind the two 64 KiB stages (8 KiB per wave: 32 rows x
-// 256 B, 16-byte chunks XOR (row & 15) — conflict-free for the row-of-4 flush reads, two-way for the 8-byte fragment writes).
+// with the epilogue knocked out). The output slabs ARE the weight's third stage (8 KiB per wave: 32 rows x 256 B, 16-byte chunks XOR (row & 15) —
+// conflict-free for the row-of-4 flush reads, two-way for the 8-byte fragment writes): the seam's prologue fills stages 0 and 1 only, and K-tile 2's
+// weight pieces go out behind the next tile's first barrier, when every wave has left its epilogue.
 // vmcnt is ONE in-order queue for LDS-DMA pieces and stores: [tile's K-tile 0 pieces][K-tile 1 pieces][previous tile's stores] is the order
 // at a seam, so the first two waits of a tile leave exactly the younger operations outstanding (their count is known on the fast path;
 // any other epilogue path declares "unknown" and the tile starts with full waits).
@@ -72,8 +77,8 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   constexpr int BMT = 32 * TA;           // tile rows: 256 (TA = 8) or 192 (TA = 6)
   constexpr int WR = 16 * TA;            // rows of one wave row
   constexpr int OPB = 256 * 128;         // LDS bytes of one operand tile (A occupies its first BMT rows)
-  constexpr int STG = 2 * OPB;
-  constexpr int SLAB0 = 2 * STG;         // the output slabs: 4 x 8 KiB behind the stages
+  constexpr int BB = 2 * OPB;            // LDS: [A stage 0 | A stage 1 | B stage 0 | B stage 1 | B stage 2]: the activation two K-tiles deep, the WEIGHT three
+  constexpr int SLAB0 = BB + 2 * OPB;    // the output slabs (4 x 8 KiB) ARE B stage 2: free from a tile's last barrier until the next tile's first one
   constexpr int NP = TA + 8;             // LDS-DMA pieces per wave and K-tile
   constexpr int NPASS = TA / 2;          // epilogue passes of 32 rows
   constexpr int NSTORE = NPASS * 8;      // global stores per wave and tile on the interior path
@@ -119,23 +124,24 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
 #pragma unroll
   for (int q = 0; q < 8; ++q) voB[q] = (prow + 32 * q) * ldb_b + c16;
   // idx < TA: A piece idx, else B piece idx - TA (compile-time after unrolling). MAIN: K-tile t is known to be a main tile (no selects)
-  auto piece = [&](const Tile& tl, int t, int idx, auto main_tag) {
+  // `stg`: byte offset of the destination stage (A: (t & 1) OPB, B: BB + (t % 3) OPB — handed in, the callers keep t % 3 as a rolling scalar)
+  auto piece = [&](const Tile& tl, int t, int stg, int idx, auto main_tag) {
     constexpr bool MAIN = decltype(main_tag)::value;
     const bool ext = !MAIN && t < kt_ext;
     // (provably wave-uniform for hipcc: with the K-tile counter in a vector register it wrapped every piece in a waterfall loop over the scalar offset)
     const int koff = __builtin_amdgcn_readfirstlane((ext ? t : t - kt_ext) * 128);
     const bool isb = idx >= TA;
     const int q = isb ? idx - TA : idx;
-    char* dst = smem + (t & 1) * STG + (isb ? OPB : 0) + (wave + 4 * q) * 1024;
+    char* dst = smem + __builtin_amdgcn_readfirstlane(stg) + (wave + 4 * q) * 1024;
     const int vo = MAIN ? (isb ? voB[q] : voA[q]) : (prow + 32 * q) * (isb ? (ext ? ldb2_b : ldb_b) : (ext ? lda2_b : lda_b)) + c16;
     const __amdgpu_buffer_rsrc_t rs = MAIN ? (isb ? tl.rB : tl.rA) : (isb ? (ext ? tl.rB2 : tl.rB) : (ext ? tl.rA2 : tl.rA));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, koff, 0, 0);
   };
-  auto prologue = [&](const Tile& tl) {          // K-tiles 0 and 1 of a tile (the launcher guarantees >= 2 main K-tiles)
+  auto prologue = [&](const Tile& tl) {          // K-tiles 0 and 1 of a tile (the launcher guarantees >= 3 main K-tiles)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 0, q, std::false_type{}); }
+    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 0, q < TA ? 0 : BB, q, std::false_type{}); }
 #pragma unroll
-    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 1, q, std::false_type{}); }
+    for (int q = 0; q < NP; ++q) { if (!(W4X & 1)) piece(tl, 1, q < TA ? OPB : BB + OPB, q, std::false_type{}); }
   };
 
   f32x4_t acc[TA][8];
@@ -143,12 +149,12 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   const int frow_ = lane & 15, fq_ = lane >> 4;
   const int slot0 = fq_ ^ (frow_ & 7);
   const int offk[2] = {frow_ * 128 + slot0 * 16, frow_ * 128 + (slot0 ^ 4) * 16};
-  const int a_base = wm * WR * 128, b_base = OPB + wn * 128 * 128;
-  // fragment idx of substep ks out of stage `st` into set `set`: idx < 8 a B tile, else an A tile — in the order the next substep consumes
-  // them (its first row of MFMAs takes all eight B fragments and A tile 0)
-  auto fread = [&](const char* st, int ks, int set, int idx) {
-    if (idx < 8) fb[set][idx] = *reinterpret_cast<const bf16x8_t*>(st + b_base + idx * 2048 + offk[ks]);
-    else fa[set][idx - 8] = *reinterpret_cast<const bf16x8_t*>(st + a_base + (idx - 8) * 2048 + offk[ks]);
+  const int a_base = wm * WR * 128, b_base = wn * 128 * 128;
+  // fragment idx of substep ks out of the stages `sa` (activation) / `sb` (weight) into set `set`: idx < 8 a B tile, else an A tile — in the
+  // order the next substep consumes them (its first row of MFMAs takes all eight B fragments and A tile 0)
+  auto fread = [&](const char* sa, const char* sb, int ks, int set, int idx) {
+    if (idx < 8) fb[set][idx] = *reinterpret_cast<const bf16x8_t*>(sb + b_base + idx * 2048 + offk[ks]);
+    else fa[set][idx - 8] = *reinterpret_cast<const bf16x8_t*>(sa + a_base + (idx - 8) * 2048 + offk[ks]);
   };
   constexpr int NF = TA + 8;               // fragments per substep
   constexpr int NS = 8 * TA;               // MFMA slots per substep (one MFMA each)
@@ -159,34 +165,49 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   // Slot k of a substep = MFMA (i = k / 8, j = k % 8). Reads go to slots 4 r + 1 (r-th fragment), pieces to slots 4 q + 3.
   constexpr int RSTEP = NS / NF >= 4 ? 4 : NS / NF, PSTEP = NS / NP >= 4 ? 4 : NS / NP;
 
-  // one K-tile. H1: K-tile t + 1 exists (its first-substep fragments are read behind the second substep); H2: K-tile t + 2 exists (its DMA
-  // is issued behind the second substep, into the stage this K-tile leaves); MAIN2: K-tile t + 2 is a main tile for certain.
-  // `younger`: vector-memory operations issued AFTER the pieces of K-tile t + 1 that may still be in flight at the barrier (the previous
-  // tile's stores at a seam: NSTORE, or -1 = unknown -> wait for everything); 0 in the steady state
-  auto ktile = [&](const Tile& tl, int t, int younger, auto first_tag, auto h1_tag, auto h2_tag, auto main2_tag) {
-    constexpr bool H1 = decltype(h1_tag)::value, H2 = decltype(h2_tag)::value, FIRST = decltype(first_tag)::value;
-    const char* cur = smem + (t & 1) * STG;
-    const char* nxt = smem + ((t + 1) & 1) * STG;
+  // one K-tile; `bs` = t % 3, the weight's stage. H1: K-tile t + 1 exists (its first-substep fragments are read behind the second substep).
+  // H2: K-tile t + 2 exists — its ACTIVATION pieces are issued behind the second substep, into the A stage this K-tile leaves; its WEIGHT pieces went
+  // out one K-tile earlier and are the 8 youngest operations of the queue at this K-tile's barrier: they stay in flight. H3: K-tile t + 3 exists — its
+  // weight pieces are issued behind the second substep into the B stage this K-tile leaves, AFTER the activation pieces: vmcnt retires in order, so
+  // an operand only keeps a longer lead if it is the youngest in the queue when the older one is waited for. The weight is the operand that comes
+  // from HBM (a frozen weight is read once per pass; the activation was just written): two K-tiles of lead for it, one for the activation.
+  // MAIN: K-tiles t + 2 and t + 3 are main tiles for certain.
+  // `younger`: vector-memory operations issued between the pieces of K-tile 1 and the weight pieces of K-tile 2 that may still be in flight at the
+  // first K-tile's barrier (the previous tile's stores at a seam: NSTORE, or -1 = unknown -> they are waited for)
+  auto ktile = [&](const Tile& tl, int t, int bs, int younger, auto first_tag, auto h1_tag, auto h2_tag, auto h3_tag, auto main_tag) {
+    constexpr bool H1 = decltype(h1_tag)::value, H2 = decltype(h2_tag)::value, H3 = decltype(h3_tag)::value, FIRST = decltype(first_tag)::value;
+    const int sa_off = (t & 1) * OPB, sb_off = BB + bs * OPB;
+    const char* curA = smem + sa_off;
+    const char* curB = smem + sb_off;
+    const char* nxtA = smem + (OPB - sa_off);
+    const char* nxtB = smem + BB + (bs == 2 ? 0 : bs + 1) * OPB;
     // ---- substep 0: MFMAs from set 0, second-substep fragments into set 1 (the reads end well in front of the barrier's lgkmcnt(0))
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       w4_mfma(acc[k / 8][k % 8], fb[0][k % 8], fa[0][k / 8]);
-      if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(cur, 1, 1, k / RSTEP);
+      if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(curA, curB, 1, 1, k / RSTEP);
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (H1 && !(W4X & 4)) {
-      // every read of the current stage has returned; this wave's pieces of K-tile t + 1 have landed; then everybody's
-      if (FIRST && younger == NSTORE) { if constexpr (NSTORE == 32) asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // every read of the current stages has returned; this wave's pieces of K-tile t + 1 have landed (the weight pieces of K-tile t + 2 behind
+      // them may not have); then everybody's
+      constexpr int KEEP = H2 ? 8 : 0;
+      if (FIRST && younger == NSTORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTORE + KEEP) : "memory");
+      else if (FIRST && younger == 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(16 + KEEP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- substep 1: MFMAs from set 1, K-tile t + 1's first fragments into set 0, K-tile t + 2's DMA into the vacated stage
+    // ---- substep 1: MFMAs from set 1, K-tile t + 1's first fragments into set 0, the DMA of K-tile t + 2 (activation) and t + 3 (weight)
+    // into the stages just vacated
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       w4_mfma(acc[k / 8][k % 8], fb[1][k % 8], fa[1][k / 8]);
-      if constexpr (H1) { if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(nxt, 0, 0, k / RSTEP); }
-      if constexpr (H2) { if (k % PSTEP == PSTEP - 1 && k / PSTEP < NP && !(W4X & 1)) piece(tl, t + 2, k / PSTEP, main2_tag); }
+      if constexpr (H1) { if (k % RSTEP == 1 && k / RSTEP < NF && !(W4X & 2)) fread(nxtA, nxtB, 0, 0, k / RSTEP); }
+      if (k % PSTEP == PSTEP - 1 && k / PSTEP < NP && !(W4X & 1)) {
+        if constexpr (H2) { if (k / PSTEP < TA) piece(tl, t + 2, sa_off, k / PSTEP, main_tag); }
+        if constexpr (H3) { if (k / PSTEP >= TA) piece(tl, t + 3, sb_off, k / PSTEP, main_tag); }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -202,23 +223,31 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
       for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // K-tile 0 has landed (K-tile 1's pieces and, at a seam, the previous tile's stores are younger and may stay in flight)
     if (W4X & 1) {}
-    else if (younger == NSTORE) { if constexpr (NP + NSTORE == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); }
-    else if (younger == 0) { if constexpr (NP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+    else if (younger == NSTORE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NSTORE) : "memory");
+    else if (younger == 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + 16) : "memory");
+    else if (younger == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the weight's third stage: K-tile 2's weight pieces go out HERE, behind the tile's first barrier — the stage is the previous tile's slab area, and
+    // every wave of the workgroup has left its epilogue now
+    if (!(W4X & 1)) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) fread(smem, 0, 0, f);
+      for (int q = TA; q < NP; ++q) piece(cur, 2, BB + 2 * OPB, q, std::false_type{});
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fread(smem, smem + BB, 0, 0, f);
 
     // (the scale of the LoRA extension sits BETWEEN the loops, never inside one: see the eight-wave form. The launcher sends a call here only
-    // with >= 2 main K-tiles behind the extension, so every extension tile has two successors and runs the full body)
-    // (the first K-tile of a tile is peeled: it alone looks at `younger`; kt_total >= 3 when there is an extension, >= 2 without. ONE copy of
-    // the main loop and of the two tail bodies serves both cases: with a copy per case hipcc's allocation of the extension case's copy spilled)
+    // with >= 3 main K-tiles, so every extension tile has three successors and runs the full body; without an extension kt_total >= 3)
+    // (the first K-tile of a tile is peeled: it alone looks at `younger`. ONE copy of the main loop and of the three tail bodies serves both
+    // cases: with a copy per case hipcc's allocation of the extension case's copy spilled)
     const std::true_type yes{};
     const std::false_type no{};
-    int t = 1;
+    int t = 1, bs = 1;
+    auto roll = [&]() { ++t; bs = bs == 2 ? 0 : bs + 1; };
     if (kt_ext > 0) {
-      ktile(cur, 0, younger, yes, yes, yes, no);
-      for (; t < kt_ext; ++t) ktile(cur, t, 0, no, yes, yes, no);
+      ktile(cur, 0, 0, younger, yes, yes, yes, yes, no);
+      for (; t < kt_ext; roll()) ktile(cur, t, bs, 0, no, yes, yes, yes, no);
       w4_mfma_drain();
       if (p.drop_p > 0.f) {
 #pragma unroll
@@ -234,17 +263,20 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[i][j] *= p.alpha2;
       }
-    } else if (kt_total > 2) {
-      ktile(cur, 0, younger, yes, yes, yes, yes);
+    } else if (kt_total > 3) {
+      ktile(cur, 0, 0, younger, yes, yes, yes, yes, yes);
     } else {
-      ktile(cur, 0, younger, yes, yes, no, yes);
+      ktile(cur, 0, 0, younger, yes, yes, yes, no, yes);
     }
-    for (; t + 2 < kt_total; ++t) ktile(cur, t, 0, no, yes, yes, yes);
-    if (t + 1 < kt_total) { ktile(cur, t, 0, no, yes, no, yes); ++t; }
-    if (t < kt_total) ktile(cur, t, 0, no, no, no, yes);
+    for (; t + 3 < kt_total; roll()) ktile(cur, t, bs, 0, no, yes, yes, yes, yes);
+    if (t + 2 < kt_total) { ktile(cur, t, bs, 0, no, yes, yes, no, yes); roll(); }
+    if (t + 1 < kt_total) { ktile(cur, t, bs, 0, no, yes, no, no, yes); roll(); }
+    if (t < kt_total) ktile(cur, t, bs, 0, no, no, no, no, yes);
     w4_mfma_drain();
-    __builtin_amdgcn_s_barrier();          // every wave is past its last LDS read: both stages are free
+    __builtin_amdgcn_s_barrier();          // every wave is past its last LDS read: all five stages are free
 
+    // ---- the seam: the next tile's first two K-tiles go out before this tile's epilogue. Only what the epilogue needs of THIS tile stays
+    // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
     // ---- the seam: the next tile's first two K-tiles go out before this tile's epilogue. Only what the epilogue needs of THIS tile stays
     // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
     const int row0 = cur.row0, nrows = cur.nrows, n0 = cur.n0, ncols = cur.ncols, seg = cur.seg;

@@ -1,7 +1,6 @@
 """The four-wave form of the bf16 GEMM (csrc/gemm256w.hpp: one wave per SIMD, 128 x 128 wave tiles, persistent over the tile list) against the
-eight-wave form the step runs (csrc/gemm256.hip: gemm256_k). It is OFF by default (profiles/r6_gemm_w4.txt: at parity on 256-row tiles, 4-10 % ahead on
-multi-round 192-row launches, behind on single-round long-K shapes); these tests select it through `vm_gemm_w4_mode_(1)` so that the shipped kernel
-stays honest. Both forms add the K-tiles of an output element in the same order (LoRA extension tiles, then the main tiles, k ascending), so every
+eight-wave form (csrc/gemm256.hip: gemm256_k). The step runs it on the launches the scheduler gives 192-row tiles (`vm_gemm_w4_mode_(2)`, the default: -1.2 % per step;
+profiles/r6_gemm_w4.txt); these tests select it for EVERY eligible launch through `vm_gemm_w4_mode_(1)` and compare with mode 0. Both forms add the K-tiles of an output element in the same order (LoRA extension tiles, then the main tiles, k ascending), so every
 comparison is BIT FOR BIT: plain products, the LoRA K-extension with and without the input-gradient dropout mask, bias / residual epilogues, two-expert
 row segments from device counts, ragged rows and columns, 256- and 192-row tiles, one tile per workgroup and several (the seam of the persistent loop:
 the next tile's first K-tiles are requested before the epilogue and the epilogue's stores are never waited for), and repeated launches (determinism)."""
@@ -31,8 +30,8 @@ class w4:
         return self
 
     def __exit__(self, *exc):
-        from mmmm_amd import hip
-        hip.lib().vm_gemm_w4_mode_(0)
+        from mmmm_amd import hip, kernels
+        hip.lib().vm_gemm_w4_mode_(kernels.GEMM_W4)          # back to the product's setting (kernels.gemm only touches the mode when its own constant changes)
         hip.lib().vm_gemm_force_tile_(0)
 
 

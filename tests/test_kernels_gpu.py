@@ -413,7 +413,7 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
                 from mmmm_amd.models import lora as _lora
                 monkeypatch.setattr(_lora, 'FLAT_LINEAR', not on)
             elif switch == 'GEMM_W4':
-                monkeypatch.setattr(K, 'GEMM_W4', int(on))
+                monkeypatch.setattr(K, 'GEMM_W4', 1 if on else 0)
             else:
                 monkeypatch.setattr(Fh, switch, on)
             ddp.zero_grad()
@@ -432,9 +432,7 @@ def test_measured_switches_give_the_default_results(dev, K, monkeypatch, switch)
     finally:
         ddp.remove()
         if switch == 'GEMM_W4':
-            from mmmm_amd import hip as _hip
-            _hip.call('vm_gemm_w4_mode_', 0)
-            K._gemm_w4_applied[0] = 0
+            K._gemm_w4_applied[0] = -1          # the next kernels.gemm call re-applies the product's setting
 
 
 # ------------------------------------------------------------------ rope

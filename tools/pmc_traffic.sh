@@ -20,12 +20,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
         if r["Counter_Name"] != c: continue
-        m = re.search(r"(gemm256_k<[\w, ]+>|gemm_nt_k<[\w, ]+>)", r["Kernel_Name"])
+        m = re.search(r"(gemm256w?_k<[\w, ]+>|gemm_nt_k<[\w, ]+>)", r["Kernel_Name"])
         if not m: continue
         a = agg[m.group(1)]; a[0] += 1; a[1] += float(r["Counter_Value"])
     out[c] = {k: {"launches": n, "sum": v} for k, (n, v) in agg.items()}
 json.dump(out, open("gpurun_out/gemm_traffic_raw.json", "w"), indent=1)
-forms = sorted(k for k in out["FETCH_SIZE"] if k.startswith("gemm256_k<false") and "true" not in k.split(",")[-1])
+forms = sorted(k for k in out["FETCH_SIZE"] if k.startswith("gemm256w_k<") or (k.startswith("gemm256_k<false") and "true" not in k.split(",")[-1]))
 n = sum(out["FETCH_SIZE"][k]["launches"] for k in forms)
 fetch_kb = sum(out["FETCH_SIZE"][k]["sum"] for k in forms) / n
 write_kb = sum(out["WRITE_SIZE"][k]["sum"] for k in forms) / max(1, sum(out["WRITE_SIZE"][k]["launches"] for k in forms))

@@ -44,7 +44,7 @@ P('per-queue kernel time (ms): ' + ', '.join(f'q{q}: {v / 1e6:.1f}' for q, v in 
 
 
 def fam(n):
-    for key, f in (('attn_f32', 'attn f32'), ('gemm256_k', 'gemm bf16'), ('gemm_nt_k<2', 'gemm bf16'), ('gemm_nt_k<4', 'gemm f32'), ('gemm_nt_f32p_k', 'gemm f32'), ('gemm_tn_k', 'gemm bf16'), ('gemm_tn_f32', 'gemm f32'), ('lora_', 'lora'), ('tn_', 'lora'),
+    for key, f in (('attn_f32', 'attn f32'), ('gemm256_k', 'gemm bf16'), ('gemm256w_k', 'gemm bf16'), ('gemm_nt_k<2', 'gemm bf16'), ('gemm_nt_k<4', 'gemm f32'), ('gemm_nt_f32p_k', 'gemm f32'), ('gemm_tn_k', 'gemm bf16'), ('gemm_tn_f32', 'gemm f32'), ('lora_', 'lora'), ('tn_', 'lora'),
                    ('attn16', 'attn bf16'), ('a32::fwd_k', 'attn bf16'), ('fwd_k<', 'attn bf16'), ('mfma_rate_k', 'ubench'), ('attn_f32', 'attn f32'), ('attn_delta', 'attn bf16'), ('transpose', 'transpose'), ('colsum', 'colsum'), ('norm', 'norm'),
                    ('ew_k', 'elementwise'), ('gelu_tab', 'elementwise'), ('silu', 'elementwise'), ('rope', 'elementwise'), ('gather', 'rows'), ('scatter', 'rows'), ('embedding', 'rows'),
                    ('ce_', 'ce'), ('adamw', 'adamw'), ('dice', 'loss'), ('upsample', 'upsample'), ('lsap', 'loss'), ('im2col', 'patch'), ('vectorized', 'ATen'),
