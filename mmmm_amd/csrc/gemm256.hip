@@ -24,7 +24,7 @@ namespace {
 #ifndef VM_GEMM_W4_DEFAULT
 #define VM_GEMM_W4_DEFAULT 2
 #endif
-constexpr int W4_LDS_BYTES = 160 * 1024;   // four-wave form: two 64 KiB stages + 4 x 8 KiB output slabs
+constexpr int W4_LDS_BYTES = 160 * 1024;   // four-wave form: activation two K-tiles deep, weight three (the output slabs overlay its third stage)
 constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)
 constexpr int STAGE_BYTES2 = 4 * HALF_BYTES;
 constexpr int LDS_BYTES2 = 2 * STAGE_BYTES2;
