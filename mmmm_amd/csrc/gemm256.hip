@@ -534,9 +534,10 @@ __global__ __launch_bounds__(512, 2) void gemm256sk_k(const GemmParams p) {
 
 // internal (tools/ubench/gemm_w4_bench, tests, kernels.GEMM_W4): 0 = the eight-wave form everywhere, 1 = bf16 NT launches run the four-wave form (gemm256w_k),
 // 2 = only the launches the scheduler runs on 192-row tiles do (the 192-row body has no register spills and wins 3-8 % with the weight coming from HBM;
-// the 256-row body loses to the eight-wave form as soon as the launch carries a LoRA extension: profiles/r6_gemm_w4.txt, last table)
+// the 256-row body loses to the eight-wave form as soon as the launch carries a LoRA extension WITH a scale or a dropout mask: profiles/r6_gemm_w4.txt),
+// 3 = mode 2 + the 256-row launches that need no scale / mask on the extension (forward launches)
 static int& w4_mode() { static int mode = VM_GEMM_W4_DEFAULT; return mode; }
-extern "C" int vm_gemm_w4_mode_(int mode) { if (mode < 0 || mode > 2) return VM_ERR_BAD_ARG; w4_mode() = mode; return VM_OK; }
+extern "C" int vm_gemm_w4_mode_(int mode) { if (mode < 0 || mode > 3) return VM_ERR_BAD_ARG; w4_mode() = mode; return VM_OK; }
 extern "C" int vm_gemm_w4_mode_get_(void) { return w4_mode(); }
 
 // called by gemm_launch (gemm.hip) when the shape fills the chip with 256x256 tiles; f8 != 0: e4m3 main operands (vm_gemm_fp8)
@@ -549,18 +550,20 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   static std::once_flag attr_once;          // (called from the main thread and from autograd's backward thread)
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
-    const void* fns[12] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
+    const void* fns[14] = {(const void*)gemm256_k<false, 4>, (const void*)gemm256_k<true, 4>, (const void*)gemm256_k<false, 3>,
                           (const void*)gemm256_k<true, 3>, (const void*)gemm256_k<false, 4, true>, (const void*)gemm256_k<true, 4, true>,
                           (const void*)gemm256_k<false, 3, true>, (const void*)gemm256_k<true, 3, true>,
                           (const void*)gemm256_k<false, 4, false, true>, (const void*)gemm256_k<false, 3, false, true>,
-                          (const void*)gemm256w_k<8>, (const void*)gemm256w_k<6>};
+                          (const void*)gemm256w_k<8, true>, (const void*)gemm256w_k<6, true>, (const void*)gemm256w_k<8, false>, (const void*)gemm256w_k<6, false>};
     bool ok = true;
-    for (int i = 0; i < 12; ++i) ok = ok && hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 10 ? LDS_BYTES2 : W4_LDS_BYTES) == hipSuccess;
+    for (int i = 0; i < 14; ++i) ok = ok && hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i < 10 ? LDS_BYTES2 : W4_LDS_BYTES) == hipSuccess;
     attr_ok = ok;
   });
   if (!attr_ok) return VM_ERR_LAUNCH;
   const dim3 grid(p.tiles_m * p.tiles_n), block(512);
   hipStream_t st = (hipStream_t)stream;
+  // the launch needs the LoRA extension's scale / dropout mask on its accumulators (the four-wave form has an instantiation without that code)
+  const bool w4_scale = p.K2 > 0 && (p.drop_p > 0.f || p.alpha2 != 1.f);
 #define VM_G256_LAUNCH(O, M_, F_) hipLaunchKernelGGL((gemm256_k<O, M_, F_>), grid, block, LDS_BYTES2, st, p)
   if (f8 == 2) {
     if (out_f32) return VM_ERR_UNSUPPORTED;
@@ -569,14 +572,14 @@ extern "C" int vm_gemm256_launch_(const void* params, int out_f32, int segmented
   } else if (f8) {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, true); else VM_G256_LAUNCH(false, 4, true); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, true); else VM_G256_LAUNCH(false, 3, true); }
-  } else if ((w4_mode() == 1 || (w4_mode() == 2 && tile_rows == 192)) && p.K >= 192 && !out_f32 && p.act == VM_ACT_NONE) {          // (>= 3 main K-tiles: the weight is staged three deep)
+  } else if ((w4_mode() == 1 || (w4_mode() >= 2 && tile_rows == 192) || (w4_mode() == 3 && !w4_scale)) && p.K >= 192 && !out_f32 && p.act == VM_ACT_NONE) {          // (>= 3 main K-tiles: the weight is staged three deep)
     // the four-wave form (bf16 output, no fused activation) is persistent: one workgroup per CU walks the tile list (gemm256w.hpp);
     // 128 KiB of stages + 32 KiB of output slabs
     static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
     const int tiles = p.tiles_m * p.tiles_n;
     const dim3 grid4(tiles < cus ? tiles : cus), block4(256);
-    if (tile_rows == 256) hipLaunchKernelGGL((gemm256w_k<8>), grid4, block4, W4_LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((gemm256w_k<6>), grid4, block4, W4_LDS_BYTES, st, p);
+    if (tile_rows == 256) { if (w4_scale) hipLaunchKernelGGL((gemm256w_k<8, true>), grid4, block4, W4_LDS_BYTES, st, p); else hipLaunchKernelGGL((gemm256w_k<8, false>), grid4, block4, W4_LDS_BYTES, st, p); }
+    else { if (w4_scale) hipLaunchKernelGGL((gemm256w_k<6, true>), grid4, block4, W4_LDS_BYTES, st, p); else hipLaunchKernelGGL((gemm256w_k<6, false>), grid4, block4, W4_LDS_BYTES, st, p); }
   } else {
     if (tile_rows == 256) { if (out_f32) VM_G256_LAUNCH(true, 4, false); else VM_G256_LAUNCH(false, 4, false); }
     else { if (out_f32) VM_G256_LAUNCH(true, 3, false); else VM_G256_LAUNCH(false, 3, false); }

@@ -69,7 +69,7 @@ __device__ __forceinline__ void w4_mfma_drain() {
 // every reload from scratch is a vector-memory operation behind an s_waitcnt vmcnt(0) — in front of each LDS-DMA inside the K loop, and pass by
 // pass through the epilogue, where it drained the next tile's prologue and this tile's stores. Across tiles only scalars survive.
 // Returns the id of the next tile of this workgroup (< 0: none); `younger` in / out: see ktile.
-template <int TA>
+template <int TA, bool SCALE>
 __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const int id, const int id_end, const int id_step, const bool first, int& younger) {
   // (the dynamic LDS is named HERE, not handed in as a `char*`: through a generic pointer hipcc no longer saw that the LDS-DMA destination is
   // wave-uniform and wrapped every piece in a waterfall loop — guide T20)
@@ -249,7 +249,11 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
       ktile(cur, 0, 0, younger, yes, yes, yes, yes, no);
       for (; t < kt_ext; roll()) ktile(cur, t, bs, 0, no, yes, yes, yes, no);
       w4_mfma_drain();
-      if (p.drop_p > 0.f) {
+      // SCALE (compile time): the launch needs the extension's scale / dropout mask at all. Its mere PRESENCE costs the 256-row body ~5 us per tile on the
+      // path that skips it (hipcc places 25 accumulator-quad spill stores and 156 accumulator reads in front of the branch), so launches with
+      // alpha = 1 and no mask — every forward launch of an rsLoRA r = 64, alpha = 8 model — run an instantiation without it
+      if constexpr (!SCALE) {
+      } else if (__builtin_expect(p.drop_p > 0.f, 0)) {
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -257,7 +261,7 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
             gemm_ext_scale4<true>(p, cur.row0 + wm * WR + i * 16 + frow_, cur.n0 + wn * 128 + j * 16 + fq_ * 4, acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);       // one tile's hash at a time: interleaved for ILP, the 64 hashes spilled the accumulators
           }
-      } else if (p.alpha2 != 1.f) {
+      } else if (__builtin_expect(p.alpha2 != 1.f, 0)) {
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -383,7 +387,7 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   }
 }
 
-template <int TA>
+template <int TA, bool SCALE = true>
 __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p) {
   // ---- the tile list of this workgroup. The one-tile-per-workgroup kernels give XCD x (blocks b with b % 8 == x share an L2) one CONTIGUOUS
   // chunk of the GROUP_M-grouped tile order and the dispatcher walks every chunk front to back, 32 tiles at a time: consecutive rounds of an
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p) {
   while (id >= 0) {
     int tid_l = threadIdx.x;
     asm volatile("" : "+v"(tid_l));
-    id = w4_tile<TA>(p, tid_l, id, id_end, id_step, first, younger);
+    id = w4_tile<TA, SCALE>(p, tid_l, id, id_end, id_step, first, younger);
     first = false;
   }
 }
