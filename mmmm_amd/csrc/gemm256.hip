@@ -22,7 +22,7 @@
 namespace {
 
 #ifndef VM_GEMM_W4_DEFAULT
-#define VM_GEMM_W4_DEFAULT 2
+#define VM_GEMM_W4_DEFAULT 3
 #endif
 constexpr int W4_LDS_BYTES = 160 * 1024;   // four-wave form: activation two K-tiles deep, weight three (the output slabs overlay its third stage)
 constexpr int HALF_BYTES = 128 * 128;      // 128 rows x 128 B (64 bf16)

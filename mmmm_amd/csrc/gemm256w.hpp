@@ -308,12 +308,19 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
       const bool interior = rows_left >= WR && cols_left >= 128 && vec_ok;
       // bias of the lane's column groups (guarded element loads: once per tile, any alignment, ragged N)
       f32x4_t bv[8];
+      if (bias && cols_left >= 128 && (((uintptr_t)bias + 2 * (uintptr_t)n0) & 7) == 0) {
+        // full-width column block, 8-byte aligned: eight vector loads in flight together (the guarded form below is 32 dependent round trips:
+        // ~4 us per tile on the ViT-E fc1 shape, where the eight-wave form's epi_bias4 path costs 0.5)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (bias) {
+        for (int j = 0; j < 8; ++j) bv[j] = epi_bias4(bias, n0 + wn * 128 + j * 16 + fq * 4);
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const int c = j * 16 + fq * 4 + e; if (c < cols_left) bv[j][e] = bf2f(bias[n0 + wn * 128 + c]); }
+        for (int j = 0; j < 8; ++j) {
+          bv[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int c = j * 16 + fq * 4 + e; if (c < cols_left) bv[j][e] = bf2f(bias[n0 + wn * 128 + c]); }
+          }
         }
       }
       const int ch = lane_e & 15, rr = lane_e >> 4;             // flush: 16 chunks of 16 B per row, 4 rows per wave-instruction

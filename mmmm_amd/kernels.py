@@ -32,9 +32,10 @@ def _ld(t: torch.Tensor) -> int:
 _GEMM_WS: dict = {}
 GEMM_TAILS = True            # the scheduler may run a launch as full 256-row tiles + a tails launch (vm_gemm_tails_mode_); A/B: bench.py --set kernels.GEMM_TAILS=False
 _gemm_tails_applied = [True]
-GEMM_W4 = 2                  # which launches of the 256-column kernel run the four-wave persistent form (vm_gemm_w4_mode_): 0 none, 1 all bf16-output NT launches, 2 (default) those the scheduler runs
-                             # on 192-row tiles — A B C A B C inside the step: 297.8 (0) / 294.2 (2) / 302.2 (1) ms; bit-identical results (profiles/r6_gemm_w4.txt); A/B: bench.py --set kernels.GEMM_W4=0
-_gemm_w4_applied = [2]       # (the library's own default)
+GEMM_W4 = 3                  # which launches of the 256-column kernel run the four-wave persistent form (vm_gemm_w4_mode_): 0 none, 1 all bf16-output NT launches, 2 those the scheduler runs on
+                             # 192-row tiles, 3 (default) those + the 256-row launches whose LoRA extension needs no scale / dropout mask (the forward launches) — inside the step, one call:
+                             # 301.0 (0) / 295.6 (2) / 293.4 (3) ms; bit-identical results (profiles/r6_gemm_w4.txt); A/B: bench.py --set kernels.GEMM_W4=0
+_gemm_w4_applied = [3]       # (the library's own default)
 
 
 def gemm_workspace() -> torch.Tensor:

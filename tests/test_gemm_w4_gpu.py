@@ -1,5 +1,5 @@
 """The four-wave form of the bf16 GEMM (csrc/gemm256w.hpp: one wave per SIMD, 128 x 128 wave tiles, persistent over the tile list) against the
-eight-wave form (csrc/gemm256.hip: gemm256_k). The step runs it on the launches the scheduler gives 192-row tiles (`vm_gemm_w4_mode_(2)`, the default: -1.2 % per step;
+eight-wave form (csrc/gemm256.hip: gemm256_k). The step runs it on the launches the scheduler gives 192-row tiles and on the 256-row launches without a scale / mask on the LoRA extension (`vm_gemm_w4_mode_(3)`, the default: -2.5 % per step;
 profiles/r6_gemm_w4.txt); these tests select it for EVERY eligible launch through `vm_gemm_w4_mode_(1)` and compare with mode 0. Both forms add the K-tiles of an output element in the same order (LoRA extension tiles, then the main tiles, k ascending), so every
 comparison is BIT FOR BIT: plain products, the LoRA K-extension with and without the input-gradient dropout mask, bias / residual epilogues, two-expert
 row segments from device counts, ragged rows and columns, 256- and 192-row tiles, one tile per workgroup and several (the seam of the persistent loop:
