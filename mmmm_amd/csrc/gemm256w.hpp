@@ -87,7 +87,8 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   const int wm = wave >> 1, wn = wave & 1;
   struct Tile { int row0, nrows, seg, n0, ncols; __amdgpu_buffer_rsrc_t rA, rB, rA2, rB2; };
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
-  const int kt_ext = p.K2 / 64, kt_total = kt_ext + p.K / 64;
+  // (scalars, said so: as plain ints hipcc kept `kt_ext > 0` as a 0 / 1 VECTOR value across the tile loop, spilled it, and reloaded it per tile behind a vmcnt(0))
+  const int kt_ext = __builtin_amdgcn_readfirstlane(p.K2 / 64), kt_total = __builtin_amdgcn_readfirstlane(kt_ext + p.K / 64);
   const int lda2_b = kt_ext ? (int)p.lda2 * 2 : 0, ldb2_b = kt_ext ? (int)p.ldb2 * 2 : 0;
   // rows / columns of tile `id`; false: the tile has no rows (the token-routed form launches an upper bound of tile rows)
   auto locate = [&](int id, Tile& tl) -> bool {
@@ -230,9 +231,17 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
     __builtin_amdgcn_s_barrier();
     // the weight's third stage: K-tile 2's weight pieces go out HERE, behind the tile's first barrier — the stage is the previous tile's slab area, and
     // every wave of the workgroup has left its epilogue now
+    // (K-tile 2 is a main tile unless the extension is more than two K-tiles deep: the MAIN form uses the per-piece offsets the K loop keeps in registers.
+    // The generic form's base offset was spilled by the 256-row body and reloaded HERE behind an s_waitcnt vmcnt(0) — which waited for the previous
+    // tile's stores, the very thing the seam is built to avoid)
     if (!(W4X & 1)) {
+      if (kt_ext <= 2) {
 #pragma unroll
-      for (int q = TA; q < NP; ++q) piece(cur, 2, BB + 2 * OPB, q, std::false_type{});
+        for (int q = TA; q < NP; ++q) piece(cur, 2, BB + 2 * OPB, q, std::true_type{});
+      } else {
+#pragma unroll
+        for (int q = TA; q < NP; ++q) piece(cur, 2, BB + 2 * OPB, q, std::false_type{});
+      }
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) fread(smem, smem + BB, 0, 0, f);
@@ -395,7 +404,16 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
 }
 
 template <int TA, bool SCALE = true>
-__global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p) {
+__global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p_in) {
+  // the token-routed form keeps its segment boundary and row count on the device: read ONCE per workgroup here (gemm_tile_rows would load them for every
+  // tile of the persistent loop — a global load and an s_waitcnt vmcnt(0) at every seam, which waited for the previous tile's stores and the prologue)
+  GemmParams p = p_in;
+  if (p.counts_dev) {
+    const int c0 = __builtin_amdgcn_readfirstlane(p.counts_dev[0]), c1 = __builtin_amdgcn_readfirstlane(p.counts_dev[1]);
+    p.split = c0;
+    p.M = min(p.M, c1);
+    p.counts_dev = nullptr;
+  }
   // ---- the tile list of this workgroup. The one-tile-per-workgroup kernels give XCD x (blocks b with b % 8 == x share an L2) one CONTIGUOUS
   // chunk of the GROUP_M-grouped tile order and the dispatcher walks every chunk front to back, 32 tiles at a time: consecutive rounds of an
   // XCD are neighbours in tile space (shared operand panels still in its L2 / the Infinity Cache). Same walk here: workgroup (x = b % 8,
@@ -429,9 +447,13 @@ __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p) {
   if constexpr (W4X & 64) {       // experiment: XCD x starts x * ~3 us late (are the epilogues' store bursts a chip-wide collision?)
     for (int k = 0; k < (int)(blockIdx.x & 7) * 6; ++k) __builtin_amdgcn_s_sleep(16);
   }
+  // (the thread id is REBUILT per tile — wave index from a scalar, lane from mbcnt — instead of being kept: the 256-row body kept it in scratch, and its reload
+  // at the loop header sat behind an s_waitcnt vmcnt(0) that waited for the previous tile's stores and the prologue every time round)
+  const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   while (id >= 0) {
-    int tid_l = threadIdx.x;
-    asm volatile("" : "+v"(tid_l));
+    int lane_l;           // (volatile: as a pure builtin the lane id is loop-invariant, gets hoisted, kept — and spilled again)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
+    int tid_l = wave_s * 64 + lane_l;
     id = w4_tile<TA, SCALE>(p, tid_l, id, id_end, id_step, first, younger);
     first = false;
   }
