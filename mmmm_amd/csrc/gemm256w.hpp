@@ -70,7 +70,7 @@ __device__ __forceinline__ void w4_mfma_drain() {
 // pass through the epilogue, where it drained the next tile's prologue and this tile's stores. Across tiles only scalars survive.
 // Returns the id of the next tile of this workgroup (< 0: none); `younger` in / out: see ktile.
 template <int TA, bool SCALE>
-__device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const int id, const int id_end, const int id_step, const bool first, int& younger) {
+__device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const int id, const int id_end, const int id_step, const bool first, int& younger, int (&rc)[5]) {
   // (the dynamic LDS is named HERE, not handed in as a `char*`: through a generic pointer hipcc no longer saw that the LDS-DMA destination is
   // wave-uniform and wrapped every piece in a waterfall loop — guide T20)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -213,8 +213,11 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
     }
   };
 
+  // `rc` in: rows / columns of THIS tile (row0, nrows, seg, n0, ncols) — found by the caller for the first tile, by the previous tile's seam for the others (the
+  // three integer divisions of `locate` at the loop head needed a scalar that the 256-row body kept in scratch: one more reload behind a vmcnt(0) that waited
+  // for the previous tile's stores); out: the next tile's
   Tile cur;
-  locate(id, cur);
+  cur.row0 = rc[0]; cur.nrows = rc[1]; cur.seg = rc[2]; cur.n0 = rc[3]; cur.ncols = rc[4];
   describe(cur);
   if (first) prologue(cur);
   {
@@ -294,7 +297,7 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
     // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
     const int row0 = cur.row0, nrows = cur.nrows, n0 = cur.n0, ncols = cur.ncols, seg = cur.seg;
     const int nid = find(id + id_step, cur);
-    if (nid >= 0) { describe(cur); prologue(cur); }
+    if (nid >= 0) { describe(cur); prologue(cur); rc[0] = cur.row0; rc[1] = cur.nrows; rc[2] = cur.seg; rc[3] = cur.n0; rc[4] = cur.ncols; }
 
     // ---- epilogue: accumulators (+ bias) -> bf16 -> this wave's slab -> whole 256-byte rows of C (+ residual), 32 rows per pass
     int stores = -1;                       // global stores this wave issued for the tile, if the path knows (-1: unknown)
@@ -435,12 +438,13 @@ __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p_in) {
   }
   // first tile with rows (the token-routed form launches an upper bound of tile rows)
   int id = -1;
+  int rc[5] = {0, 0, 0, 0, 0};
   for (int c = id0; c < id_end; c += id_step) {
     const int per_group = GROUP_M * p.tiles_n;
     const int g = c / per_group, gm0 = g * GROUP_M, gsz = min(GROUP_M, p.tiles_m - gm0), rem = c - g * per_group;
     int row0, nrows, seg;
     gemm_tile_rows<BMT>(p, gm0 + rem % gsz, row0, nrows, seg);
-    if (nrows > 0) { id = c; break; }
+    if (nrows > 0) { id = c; rc[0] = row0; rc[1] = nrows; rc[2] = seg; rc[3] = (rem / gsz) * 256; rc[4] = min(256, p.N - rc[3]); break; }
   }
   int younger = 0;            // operations behind the two prologue K-tiles in the queue: none for the first tile
   bool first = true;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w_k(const GemmParams p_in) {
     int lane_l;           // (volatile: as a pure builtin the lane id is loop-invariant, gets hoisted, kept — and spilled again)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
     int tid_l = wave_s * 64 + lane_l;
-    id = w4_tile<TA, SCALE>(p, tid_l, id, id_end, id_step, first, younger);
+    id = w4_tile<TA, SCALE>(p, tid_l, id, id_end, id_step, first, younger, rc);
     first = false;
   }
 }
