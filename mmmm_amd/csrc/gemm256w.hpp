@@ -293,8 +293,6 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
 
     // ---- the seam: the next tile's first two K-tiles go out before this tile's epilogue. Only what the epilogue needs of THIS tile stays
     // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
-    // ---- the seam: the next tile's first two K-tiles go out before this tile's epilogue. Only what the epilogue needs of THIS tile stays
-    // live (five scalars); the next tile's descriptors are rebuilt at the loop head (scalar work) instead of living across the epilogue.
     const int row0 = cur.row0, nrows = cur.nrows, n0 = cur.n0, ncols = cur.ncols, seg = cur.seg;
     const int nid = find(id + id_step, cur);
     if (nid >= 0) { describe(cur); prologue(cur); rc[0] = cur.row0; rc[1] = cur.nrows; rc[2] = cur.seg; rc[3] = cur.n0; rc[4] = cur.ncols; }
