@@ -85,10 +85,11 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  struct Tile { int row0, nrows, seg, n0, ncols; __amdgpu_buffer_rsrc_t rA, rB, rA2, rB2; };
+  struct Tile { int row0, nrows, seg, n0, ncols; __amdgpu_buffer_rsrc_t rA, rB; };          // (the extension's descriptors are built where they are used: K-tile 0's pieces)
   const int lda_b = (int)p.lda * 2, ldb_b = (int)p.ldb * 2;
   // (scalars, said so: as plain ints hipcc kept `kt_ext > 0` as a 0 / 1 VECTOR value across the tile loop, spilled it, and reloaded it per tile behind a vmcnt(0))
-  const int kt_ext = __builtin_amdgcn_readfirstlane(p.K2 / 64), kt_total = __builtin_amdgcn_readfirstlane(kt_ext + p.K / 64);
+  int kt_ext = p.K2 / 64, kt_total = p.K2 / 64 + p.K / 64;
+  asm volatile("" : "+s"(kt_ext), "+s"(kt_total));          // pinned to the scalar file (readfirstlane took the detour through a vector register — which was then kept, and spilled)
   const int lda2_b = kt_ext ? (int)p.lda2 * 2 : 0, ldb2_b = kt_ext ? (int)p.ldb2 * 2 : 0;
   // rows / columns of tile `id`; false: the tile has no rows (the token-routed form launches an upper bound of tile rows)
   auto locate = [&](int id, Tile& tl) -> bool {
@@ -103,11 +104,6 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
   auto describe = [&](Tile& tl) {
     tl.rA = make_rsrc(p.A, (int64_t)tl.row0 * lda_b, tl.nrows * lda_b);
     tl.rB = make_rsrc(tl.seg ? p.B1 : p.B0, (int64_t)tl.n0 * ldb_b, tl.ncols * ldb_b);
-    tl.rA2 = tl.rA; tl.rB2 = tl.rB;
-    if (kt_ext > 0) {
-      tl.rA2 = make_rsrc(p.A2, (int64_t)tl.row0 * lda2_b, tl.nrows * lda2_b);
-      tl.rB2 = make_rsrc(tl.seg ? p.B2_1 : p.B2_0, (int64_t)tl.n0 * ldb2_b, tl.ncols * ldb2_b);
-    }
   };
   auto find = [&](int id, Tile& tl) -> int {      // first tile with rows at or after `id` in this workgroup's list, -1: none
     for (; id < id_end; id += id_step)
@@ -135,7 +131,10 @@ __device__ __forceinline__ int w4_tile(const GemmParams& p, const int tid, const
     const int q = isb ? idx - TA : idx;
     char* dst = smem + __builtin_amdgcn_readfirstlane(stg) + (wave + 4 * q) * 1024;
     const int vo = MAIN ? (isb ? voB[q] : voA[q]) : (prow + 32 * q) * (isb ? (ext ? ldb2_b : ldb_b) : (ext ? lda2_b : lda_b)) + c16;
-    const __amdgpu_buffer_rsrc_t rs = MAIN ? (isb ? tl.rB : tl.rA) : (isb ? (ext ? tl.rB2 : tl.rB) : (ext ? tl.rA2 : tl.rA));
+    __amdgpu_buffer_rsrc_t rs = isb ? tl.rB : tl.rA;
+    if constexpr (!MAIN) {
+      if (ext) rs = isb ? make_rsrc(tl.seg ? p.B2_1 : p.B2_0, (int64_t)tl.n0 * ldb2_b, tl.ncols * ldb2_b) : make_rsrc(p.A2, (int64_t)tl.row0 * lda2_b, tl.nrows * lda2_b);
+    }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, koff, 0, 0);
   };
   auto prologue = [&](const Tile& tl) {          // K-tiles 0 and 1 of a tile (the launcher guarantees >= 3 main K-tiles)
